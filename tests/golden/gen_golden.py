@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (it imports /root/reference, which never
+travels to the GPU box).  It calls the reference's own method bodies
+(``method.__wrapped__`` -- the way upstream tests do, tests/merge_methods/
+test_ties.py:29) and ``sd_mecha.merge`` on small seeded inputs, and stores
+inputs + expected outputs as data in ``.npz`` files.  No reference source text
+is stored.
+
+    python tests/golden/gen_golden.py        # rewrites tests/golden/*.npz
+
+Bootstrap: ``fuzzywuzzy`` is not installed and is used by
+the reference only to decorate error messages, so a two-line stand-in module is
+registered before the import.
+"""
+import pathlib
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+
+fw = types.ModuleType("fuzzywuzzy")
+fwp = types.ModuleType("fuzzywuzzy.process")
+fwp.extractOne = lambda q, choices, **k: (next(iter(choices), None), 0)
+fw.process = fwp
+sys.modules["fuzzywuzzy"] = fw
+sys.modules["fuzzywuzzy.process"] = fwp
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+import sd_mecha  # noqa: E402
+from sd_mecha.extensions.builtin.merge_methods import linear, ties, svd  # noqa: E402
+from sd_mecha.extensions.builtin import lycoris  # noqa: E402
+
+TDT = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}
+SHAPES = [(), (0,), (7,), (33, 7), (64, 96), (8, 4, 3, 3), (1, 1)]
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """Bit pattern of a torch tensor as a numpy array (uint16 for half types, uint32 view for fp32)."""
+    t = t.detach().contiguous().cpu()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy().view(np.uint16).copy()
+    if t.dtype == torch.float32:
+        return t.numpy().view(np.uint32).copy()
+    raise TypeError(t.dtype)
+
+
+def rand_half(rng, shape, dtype, std=0.02) -> torch.Tensor:
+    x = torch.from_numpy(rng.normal(0.0, std, size=shape).astype(np.float32))
+    return x.to(TDT[dtype])
+
+
+def sd(t):
+    """StateDict-typed parameters accept a plain dict plus key=."""
+    return {"k": t}
+
+
+def gen_streaming(out):
+    rng = np.random.default_rng(20260424)
+    case = 0
+    for shape in SHAPES:
+        for dtype in ("bfloat16", "float16"):
+            a, b, c = (rand_half(rng, shape, dtype) for _ in range(3))
+            af, bf, cf = a.float(), b.float(), c.float()
+            pre = f"s{case}"
+            out[pre + "_a"], out[pre + "_b"], out[pre + "_c"] = bits(a), bits(b), bits(c)
+            out[pre + "_dtype"] = np.array(dtype)
+            out[pre + "_shape"] = np.array(shape, dtype=np.int64)
+            for alpha in (0.5, 0.3, 0.75, 0.0, 1.0):
+                al = torch.tensor(alpha, dtype=torch.float32)
+                out[f"{pre}_wsum_{alpha}"] = bits(linear.weighted_sum.__wrapped__(sd(af), sd(bf), al, key="k"))
+                out[f"{pre}_adddiff_{alpha}"] = bits(linear.add_difference.__wrapped__(sd(af), sd(bf), al, key="k"))
+            out[pre + "_sub"] = bits(linear.subtract.__wrapped__(af, bf))
+            out[pre + "_scale_0.7"] = bits(linear.scale.__wrapped__(sd(af), torch.tensor(0.7), key="k"))
+            for n in (2, 3, 8):
+                ms = [a, b, c] + [rand_half(rng, shape, dtype) for _ in range(n - 3)] if n > 3 else [a, b, c][:n]
+                if n > 3:
+                    for j, m in enumerate(ms[3:]):
+                        out[f"{pre}_navg{n}_extra{j}"] = bits(m)
+                out[f"{pre}_navg{n}"] = bits(linear.n_average.__wrapped__(*[sd(m.float()) for m in ms], key="k"))
+            if len(shape) > 0 and int(np.prod(shape)) > 1:
+                for alpha in (0.5, 0.3):
+                    out[f"{pre}_slerp_{alpha}"] = bits(linear.slerp.__wrapped__(af, bf, torch.tensor(alpha)))
+                out[pre + "_perp"] = bits(linear.perpendicular_component.__wrapped__(af, bf))
+                # add_perpendicular graph (wrappers.py:42-64) from primitives
+                ad, bd = linear.subtract.__wrapped__(af, cf), linear.subtract.__wrapped__(bf, cf)
+                perp = linear.perpendicular_component.__wrapped__(ad, bd)
+                out[pre + "_addperp_1.0"] = bits(linear.add_difference.__wrapped__(sd(af), sd(perp), torch.tensor(1.0), key="k"))
+            # output casts (root cast node, merging.py:157-158)
+            r = linear.weighted_sum.__wrapped__(sd(af), sd(bf), torch.tensor(0.3), key="k")
+            out[pre + "_wsum_0.3_as_bf16"] = bits(r.to(torch.bfloat16))
+            out[pre + "_wsum_0.3_as_f16"] = bits(r.to(torch.float16))
+            case += 1
+    out["n_cases"] = np.array(case)
+
+
+def gen_ties(out):
+    rng = np.random.default_rng(1708)
+    case = 0
+    combos = [(shape, n, "bfloat16") for shape in [(7,), (33, 7), (64, 48), (8, 4, 3, 3), (1, 1)] for n in (2, 3, 7)]
+    combos += [((33, 7), 3, "float16"), ((64, 48), 7, "float16"), ((129, 65), 3, "bfloat16")]
+    for shape, n_models, dtype in combos:
+        base = rand_half(rng, shape, dtype)
+        models = [rand_half(rng, shape, dtype) for _ in range(n_models)]
+        pre = f"t{case}"
+        out[pre + "_base"] = bits(base)
+        out[pre + "_models"] = np.stack([bits(m) for m in models])
+        out[pre + "_dtype"] = np.array(dtype)
+        deltas = [linear.subtract.__wrapped__(m.float(), base.float()) for m in models]
+        for k in (0.2, 0.5, 1.0):
+            numel = deltas[0].numel()
+            kth = max(int((1 - k) * numel), 1)
+            thr = [d.flatten().abs().float().kthvalue(kth)[0] for d in deltas]
+            out[f"{pre}_k{k}_kth"] = np.array(kth)
+            out[f"{pre}_k{k}_thr"] = np.stack([bits(t) for t in thr])
+            keep = np.stack([(d.abs() >= t).numpy() for d, t in zip(deltas, thr)])
+            out[f"{pre}_k{k}_keep"] = np.packbits(keep.reshape(n_models, -1), axis=1)
+            for vote in ((False, True) if k == 0.2 else (False,)):
+                filt, counts = ties.ties_sum_deltas(*deltas, k=k, vote_sgn=vote)
+                stacked = torch.stack([ties.filter_top_k(d, k) for d in deltas])
+                fsign = torch.sign(torch.sum(stacked if vote else torch.sign(stacked), dim=0))
+                res = ties.ties_sum.__wrapped__(*deltas, k=k, vote_sgn=vote)
+                out[f"{pre}_k{k}_v{int(vote)}_out"] = bits(res)
+                out[f"{pre}_k{k}_v{int(vote)}_sign"] = fsign.numpy().astype(np.int8)
+                out[f"{pre}_k{k}_v{int(vote)}_count"] = counts.numpy().astype(np.uint8)
+                if not vote:
+                    merged = linear.add_difference.__wrapped__(sd(base.float()), sd(res), torch.tensor(1.0), key="k")
+                    out[f"{pre}_k{k}_merged_{'bf16' if dtype == 'bfloat16' else 'f16'}"] = bits(merged.to(TDT[dtype]))
+        case += 1
+    out["n_cases"] = np.array(case)
+    # upstream known-answer vectors are re-stated in tests/test_oracle_golden.py (they are data in upstream tests)
+
+
+def gen_dare(out):
+    rng = np.random.default_rng(114514)
+    case = 0
+    for shape in [(16,), (33, 7), (48, 32)]:
+        for n_models in (2, 3):
+            deltas = [torch.from_numpy(rng.normal(0, 0.02, size=shape).astype(np.float32)) for _ in range(n_models)]
+            for seed in (0, 114514):
+                for p in (0.4, 0.9):
+                    pre = f"d{case}"
+                    out[pre + "_deltas"] = np.stack([bits(d) for d in deltas])
+                    out[pre + "_seed"] = np.array(seed)
+                    out[pre + "_p"] = np.array(p)
+                    g = torch.Generator("cpu")
+                    g.manual_seed(seed)
+                    masks = [ties.find_della_dropout(d, torch.tensor(p), 0.0, g) for d in deltas]
+                    out[pre + "_masks"] = np.packbits(np.stack([m.numpy().astype(bool).reshape(-1) for m in masks]), axis=1)
+                    for apply_stock in (True, False):
+                        for rescale in (True, False):
+                            res = ties.ties_sum_with_dropout.__wrapped__(
+                                *deltas, probability=torch.tensor(p), della_eps=0.0, rescale=rescale, k=0.5,
+                                vote_sgn=False, apply_stock=apply_stock, cos_eps=1e-6, apply_median=False,
+                                eps=1e-6, maxiter=100, ftol=1e-20, seed=seed)
+                            out[f"{pre}_stock{int(apply_stock)}_rescale{int(rescale)}"] = bits(res)
+                    case += 1
+    out["n_cases"] = np.array(case)
+
+
+def gen_rotate(out):
+    rng = np.random.default_rng(360)
+    case = 0
+    for shape in [(64, 48), (32, 32), (24, 64), (8, 4, 3, 3), (48, 16, 1, 1), (12,)]:
+        a = torch.from_numpy(rng.normal(0, 0.02, size=shape).astype(np.float32)).to(torch.bfloat16).float()
+        b = torch.from_numpy(rng.normal(0, 0.02, size=shape).astype(np.float32)).to(torch.bfloat16).float()
+        pre = f"r{case}"
+        out[pre + "_a"], out[pre + "_b"] = bits(a), bits(b)
+        for alpha in (0.0, 0.5):
+            for cz in (1.0, 0.0):
+                res = svd.rotate.__wrapped__(sd(a), sd(b), alignment=1.0, alpha=torch.tensor(alpha), centralization=cz, key="k")
+                out[f"{pre}_out_alpha{alpha}_cz{cz}"] = bits(res)
+        if len(shape) >= 2:
+            is_conv = len(shape) == 4 and int(np.prod(shape[-2:])) != 1
+            s2 = (int(np.prod(shape[:2])), int(np.prod(shape[2:]))) if is_conv else (shape[0], int(np.prod(shape[1:])))
+            a2, b2 = a.reshape(s2), b.reshape(s2)
+            a2 = a2 - a2.mean(0)
+            b2 = b2 - b2.mean(0)
+            tr = svd.orthogonal_procrustes(a2, b2)
+            eye = torch.eye(s2[1])
+            out[pre + "_R"] = bits(tr(eye, 1.0))        # the p x p matrix the transform applies (I @ R)
+        case += 1
+    out["n_cases"] = np.array(case)
+
+
+def gen_lora(out):
+    rng = np.random.default_rng(16)
+    cases = [((64, 8), (8, 48), (64, 48)), ((32, 8, 1, 1), (8, 16, 3, 3), (32, 16, 3, 3)), ((160, 8), (8, 192), (160, 192))]
+    for i, (us, ds, ts) in enumerate(cases):
+        up = rand_half(rng, us, "float16", std=0.05)
+        down = rand_half(rng, ds, "float16", std=0.05)
+        alpha = torch.tensor(4.0, dtype=torch.float16)
+        state = {"lora_x.lora_up.weight": up.float(), "lora_x.lora_down.weight": down.float(), "lora_x.alpha": alpha.float()}
+        helper = lycoris.StateDictKeyHelper(state, "lora_x")
+        pre = f"l{i}"
+        out[pre + "_up"], out[pre + "_down"] = bits(up), bits(down)
+        out[pre + "_target_shape"] = np.array(ts, dtype=np.int64)
+        out[pre + "_delta_alpha4"] = bits(lycoris.LoraAlgorithm.compose_alpha(helper, torch.Size(ts)))
+        out[pre + "_delta_noalpha"] = bits(lycoris.LoraAlgorithm.compose(helper, torch.Size(ts)))
+        base = rand_half(rng, ts, "bfloat16")
+        out[pre + "_base"] = bits(base)
+        delta = lycoris.LoraAlgorithm.compose_alpha(helper, torch.Size(ts))
+        merged = linear.add_difference.__wrapped__(sd(base.float()), sd(delta), torch.tensor(0.75), key="k")
+        out[pre + "_merged_0.75_bf16"] = bits(merged.to(torch.bfloat16))
+    out["n_cases"] = np.array(len(cases))
+
+
+def gen_e2e(out):
+    """The whole chain through sd_mecha.merge (cast nodes, omit_non_finite, root cast) on a 4-key toy checkpoint set."""
+    import safetensors.torch
+    from tqdm import tqdm
+
+    class quiet(tqdm):
+        def __init__(self, *a, **k):
+            k["disable"] = True
+            super().__init__(*a, **k)
+
+    rng = np.random.default_rng(4)
+    shapes = {"w.linear": (128, 96), "w.conv": (32, 16, 3, 3), "w.bias": (128,), "w.scalar": ()}
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        paths = []
+        for m in range(4):
+            state = {k: rand_half(rng, s, "bfloat16") for k, s in shapes.items()}
+            if m == 3:
+                state["w.bias"][5] = float("inf")      # non-finite input: the key must be skipped where this model is read
+            p = td / f"m{m}.safetensors"
+            safetensors.torch.save_file(state, str(p))
+            paths.append(p)
+            for k, t in state.items():
+                out[f"e_m{m}_{k}"] = bits(t)
+        models = [sd_mecha.model(p) for p in paths]
+        kw = dict(threads=0, output_dtype=torch.bfloat16, tqdm=quiet)
+
+        def store(name, res):
+            res = {k: v for k, v in res.items() if k != "__metadata__"}
+            out[f"e_{name}_keys"] = np.array(sorted(res.keys()))
+            for k, v in res.items():
+                out[f"e_{name}_{k}"] = bits(v)
+
+        store("wsum", sd_mecha.merge(linear.weighted_sum(models[0], models[1], alpha=0.5), **kw))
+        store("wsum_f16", sd_mecha.merge(linear.weighted_sum(models[0], models[1], alpha=0.3), **{**kw, "output_dtype": torch.float16}))
+        store("navg3", sd_mecha.merge(linear.n_average(models[0], models[1], models[2]), **kw))
+        store("navg4", sd_mecha.merge(linear.n_average(*models), **kw))      # m3 has a non-finite bias
+        deltas = [linear.subtract(m, models[0]) for m in models[1:3]]
+        store("ties", sd_mecha.merge(linear.add_difference(models[0], ties.ties_sum(*deltas, k=0.2), alpha=1.0), **kw))
+        deltas4 = [linear.subtract(m, models[0]) for m in models[1:4]]
+        store("ties4_fallback", sd_mecha.merge(
+            linear.add_difference(models[0], ties.ties_sum(*deltas4, k=0.2), alpha=1.0) | models[0], **kw))
+    out["shapes_keys"] = np.array(list(shapes.keys()))
+
+
+def main():
+    torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
+    for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare),
+                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e)]:
+        out = {}
+        fn(out)
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(name, len(out), "arrays", (HERE / f"{name}.npz").stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    main()
