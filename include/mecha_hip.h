@@ -1,0 +1,196 @@
+/*
+ * mecha_hip.h -- C ABI of libmecha_hip.so, the MI355X (gfx950) backend for
+ * sd-mecha's per-key merge hot path.
+ *
+ * The reference (ljleb/sd-mecha v1.1.5) has no FFI of its own: the boundary it
+ * offers is the Python call MergeMethod.merge_key -> fn(*tensors, **hyper)
+ * (sd_mecha/extensions/merge_methods.py:304-337, called from
+ * sd_mecha/merging.py:418-426).  Every entry point below replaces the torch op
+ * sequence of one builtin method body reached through that call; the comment on
+ * each cites it (paths relative to /root/reference/sd_mecha).  INTEGRATION.md
+ * shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *  - All tensor pointers are DEVICE pointers to contiguous data on the current
+ *    HIP device; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *    Work is only enqueued: nothing here synchronises the device or the stream
+ *    unless its comment says so.  The library never frees or retains caller memory.
+ *  - dtypes: MECHA_F32 / MECHA_F16 / MECHA_BF16.  Arithmetic is IEEE fp32
+ *    ("merge_dtype", merging.py:116-117); inputs are upcast exactly
+ *    (logistics.py:53), outputs rounded once, to nearest even, to `out_dtype`
+ *    (root cast node, merging.py:157-158).
+ *  - `flags` (may be NULL): device uint32 word(s), OR-ed into, never cleared here.
+ *    bit 0 (MECHA_FLAG_INPUT_NONFINITE): some input element was inf/NaN -- the
+ *    caller turns it into NonFiniteStateDictKeyError = "skip this key"
+ *    (logistics.py:132-142).  bit 1 (MECHA_FLAG_OUTPUT_NONFINITE): some output
+ *    element is inf/NaN -- warning only (merging.py:297-308).
+ *  - Return value: 0 on success, negative on error; mecha_last_error() returns
+ *    the message of the calling thread's last error.
+ *  - Workspaces are caller-provided device memory sized by the *_workspace_bytes
+ *    query next to each entry point; they need no initialisation.
+ *  - Re-entrant: no global mutable state besides the per-thread error string.
+ */
+#ifndef MECHA_HIP_H
+#define MECHA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MECHA_ABI_VERSION 1
+
+#define MECHA_F32 0
+#define MECHA_F16 1
+#define MECHA_BF16 2
+
+#define MECHA_FLAG_INPUT_NONFINITE 1u
+#define MECHA_FLAG_OUTPUT_NONFINITE 2u
+
+#define MECHA_MAX_MODELS 32
+
+#define MECHA_OK 0
+#define MECHA_ERR_ARG (-1)
+#define MECHA_ERR_HIP (-2)
+#define MECHA_ERR_WORKSPACE (-3)
+
+int mecha_abi_version(void);
+const char *mecha_last_error(void);
+
+/* Per-kernel timers (no counterpart in the reference, which has no timers or profiler: SURVEY.md §5).
+ * Off by default.  While enabled, every kernel launch of the library is bracketed by HIP events recorded
+ * on the launch's own stream; mecha_profile_read(id) waits for the recorded launches and returns the summed
+ * elapsed time and the launch count of kernel family `id` (0 <= id < mecha_profile_kernel_count()).
+ * bench.py derives `roofline.achieved` from these. */
+int mecha_profile_enable(int on);
+int mecha_profile_kernel_count(void);
+const char *mecha_profile_kernel_name(int id);
+int mecha_profile_read(int id, double *total_ms, long long *launches, int reset);
+
+/* A run of elements that belongs to one state-dict key inside per-model arenas
+ * (the key scheduler's HBM layout, DESIGN.md "data layout").  `offset` is in
+ * ELEMENTS from each arena base and must be a multiple of 8; `numel` is the
+ * key's element count.  Batched entry points take a DEVICE array of these. */
+typedef struct mecha_segment {
+    int64_t offset;
+    int64_t numel;
+} mecha_segment;
+
+/* ------------------------------------------------------------------ per key
+ * One call = one state-dict key = one call of the reference method body. */
+
+/* cast (extensions/builtin/merge_methods/logistics.py:38-53) fused with the
+ * finite check of omit_non_finite (logistics.py:132-142). out may be NULL
+ * (check only). */
+int mecha_cast(const void *a, void *out, int64_t numel, int in_dtype, int out_dtype,
+               uint32_t *flags, void *stream);
+
+/* weighted_sum (extensions/builtin/merge_methods/linear.py:7-23): torch.lerp(a, b, alpha)
+ * with the alpha==0 -> a, alpha==1 -> b shortcuts of linear.py:18-21 (the shortcut
+ * paths read only that one input, as the lazy StateDict inputs of the reference do). */
+int mecha_weighted_sum(const void *a, const void *b, void *out, int64_t numel,
+                       int in_dtype, int out_dtype, float alpha, uint32_t *flags, void *stream);
+
+/* n_average (linear.py:26-40): running mean res = lerp(res, m_i, 1/i), i = 2..N.
+ * `models` is a HOST array of n_models device pointers (1 <= n_models <= MECHA_MAX_MODELS). */
+int mecha_n_average(const void *const *models, int n_models, void *out, int64_t numel,
+                    int in_dtype, int out_dtype, uint32_t *flags, void *stream);
+
+/* add_difference (linear.py:64-76): a.addcmul(b, alpha) = fma(b, alpha, a); alpha==0 -> a. */
+int mecha_add_difference(const void *a, const void *b, void *out, int64_t numel,
+                         int in_dtype, int out_dtype, float alpha, uint32_t *flags, void *stream);
+
+/* subtract (linear.py:96-101): a - b. */
+int mecha_subtract(const void *a, const void *b, void *out, int64_t numel,
+                   int in_dtype, int out_dtype, uint32_t *flags, void *stream);
+
+/* scale (linear.py:79-93): a * alpha (the alpha==0 -> python 0.0 case stays in the host shim). */
+int mecha_scale(const void *a, void *out, int64_t numel, int in_dtype, int out_dtype,
+                float alpha, uint32_t *flags, void *stream);
+
+/* slerp (linear.py:43-61), perpendicular_component (linear.py:104-113) and the
+ * add_perpendicular graph (wrappers.py:42-64: a + alpha * perp(a - c, b - c)).
+ * Two-pass: block-partial reductions into `workspace`, then the elementwise apply. */
+size_t mecha_reduce_workspace_bytes(int64_t numel);
+int mecha_slerp(const void *a, const void *b, void *out, int64_t numel, int in_dtype, int out_dtype,
+                float alpha, void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream);
+int mecha_perpendicular_component(const void *a, const void *b, void *out, int64_t numel,
+                                  int in_dtype, int out_dtype, void *workspace, size_t workspace_bytes,
+                                  uint32_t *flags, void *stream);
+int mecha_add_perpendicular(const void *a, const void *b, const void *c, void *out, int64_t numel,
+                            int in_dtype, int out_dtype, float alpha, void *workspace,
+                            size_t workspace_bytes, uint32_t *flags, void *stream);
+
+/* ties_sum (extensions/builtin/merge_methods/ties.py:98-125) over n_models deltas:
+ * per-delta magnitude threshold = kth-smallest |delta| with kth = max(int((1-k)*numel), 1)
+ * (ties.py:128-132, exact radix select on the fp32 bit pattern), sign election
+ * (sign of the sum of signs, or of the sum of deltas if vote_sgn), disjoint mean,
+ * nan_to_num.  `thresholds_out` (may be NULL): device float[n_models], receives the
+ * selected thresholds.  `deltas` is a HOST array of device pointers. */
+size_t mecha_ties_workspace_bytes(int n_models, int64_t numel);
+int mecha_ties_sum(const void *const *deltas, int n_models, void *out, int64_t numel,
+                   int in_dtype, int out_dtype, double k, int vote_sgn, float *thresholds_out,
+                   void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream);
+
+/* The TIES recipe graph of wrappers.py:70-94 in one fused pipeline:
+ *   out = add_difference(base, ties_sum(m_0 - base, ..., m_{n-1} - base, k), alpha)
+ * (subtract linear.py:101, ties_sum ties.py:98-125, add_difference linear.py:76).
+ * Reads base and every model once per radix pass and once in the merge pass;
+ * no fp32 delta is ever materialised. */
+int mecha_add_difference_ties(const void *base, const void *const *models, int n_models, void *out,
+                              int64_t numel, int in_dtype, int out_dtype, double k, float alpha,
+                              int vote_sgn, float *thresholds_out, void *workspace,
+                              size_t workspace_bytes, uint32_t *flags, void *stream);
+
+/* DARE: ties_sum_with_dropout (ties.py:10-50) with della_eps == 0, apply_median == False and
+ * apply_stock == True (t = 1, ties.py:90).  `keep_bits`: device uint32[n_models][ceil(numel/32)],
+ * bit (i & 31) of word (i >> 5) = Bernoulli keep mask of element i of that delta.  For results
+ * identical to the reference's CPU generator stream, draw them with mecha_dare_draw_masks_host.
+ * out = ties_sum(delta_m * mask_m ...) / (rescale ? 1 - probability : 1). */
+int mecha_ties_sum_with_dropout(const void *const *deltas, int n_models, const uint32_t *keep_bits,
+                                void *out, int64_t numel, int in_dtype, int out_dtype, double k,
+                                int vote_sgn, float probability, int rescale, float *thresholds_out,
+                                void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream);
+
+/* HOST function: the Bernoulli keep masks the reference draws on CPU (ties.py:29-33, :63-64):
+ * torch.Generator().manual_seed(seed), then torch.bernoulli(1 - probability) per delta in order
+ * (MT19937, one 24-bit uniform per element).  Writes bit-packed masks, layout as `keep_bits`
+ * above, into HOST memory `bits_out` (n_models * ceil(numel/32) words). */
+int mecha_dare_draw_masks_host(uint64_t seed, float probability, int n_models, int64_t numel,
+                               uint32_t *bits_out);
+
+/* ------------------------------------------------------------------ batched
+ * The key scheduler's form (replaces the per-key futures loop of merging.py:223-229
+ * for recognised recipe graphs): every model's shard lives in one arena with
+ * identical key offsets; ONE launch sequence merges n_segments keys.
+ * `arenas`: HOST array of device arena base pointers; `segments`: DEVICE array;
+ * `seg_flags` (may be NULL): DEVICE uint32[n_segments], per-key flag words. */
+int mecha_batched_weighted_sum(const void *a_arena, const void *b_arena, void *out_arena,
+                               const mecha_segment *segments, int n_segments, int64_t total_elems,
+                               int in_dtype, int out_dtype, float alpha, uint32_t *seg_flags, void *stream);
+int mecha_batched_n_average(const void *const *arenas, int n_models, void *out_arena,
+                            const mecha_segment *segments, int n_segments, int64_t total_elems,
+                            int in_dtype, int out_dtype, uint32_t *seg_flags, void *stream);
+int mecha_batched_add_difference(const void *a_arena, const void *b_arena, void *out_arena,
+                                 const mecha_segment *segments, int n_segments, int64_t total_elems,
+                                 int in_dtype, int out_dtype, float alpha, uint32_t *seg_flags, void *stream);
+
+/* Batched add_difference(base, ties_sum(m_i - base ..., k), alpha): per-key thresholds for every
+ * (key, model) pair, all keys in one launch sequence.  `segments_host` is the HOST copy of
+ * `segments` (needed to size the launches); `thresholds_out` (may be NULL): device
+ * float[n_segments][n_models]. */
+size_t mecha_batched_ties_workspace_bytes(int n_models, int n_segments, int64_t total_elems);
+int mecha_batched_add_difference_ties(const void *base_arena, const void *const *model_arenas, int n_models,
+                                      void *out_arena, const mecha_segment *segments,
+                                      const mecha_segment *segments_host, int n_segments,
+                                      int64_t total_elems, int in_dtype, int out_dtype, double k,
+                                      float alpha, int vote_sgn, float *thresholds_out, void *workspace,
+                                      size_t workspace_bytes, uint32_t *seg_flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MECHA_HIP_H */

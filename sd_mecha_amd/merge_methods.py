@@ -1,0 +1,357 @@
+"""Host-side mirror of sd-mecha's builtin merge methods for the MI355X backend.
+
+Same names, argument meaning and error behaviour as the reference's method bodies
+(``/root/reference/sd_mecha/extensions/builtin/merge_methods/{linear,ties,logistics}.py``), so a call
+``sd_mecha.ties_sum.__wrapped__(*deltas, k=k)`` reads ``sd_mecha_amd.ties_sum(*deltas, k=k)`` here.
+Tensors are torch tensors on a ROCm device; the arithmetic runs in libmecha_hip.so through the C ABI of
+``include/mecha_hip.h`` (PyTorch only provides device memory and the stream).  There is no CPU path.
+
+Differences that are extensions, not changes:
+  * inputs may be fp16/bf16 (the ``cast`` node of merging.py:673-681 is fused into the kernel); the result
+    dtype is ``out_dtype`` (default float32 = the reference's merge_dtype);
+  * ``StateDict``-typed parameters accept a tensor, or a mapping plus ``key=`` like the reference;
+  * non-finite inputs raise ``NonFiniteStateDictKeyError`` (logistics.py:132-142) when ``check_finite``
+    is true (one device sync); the scheduler passes ``flags=`` instead and checks once per batch.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Mapping, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, FLAG_INPUT_NONFINITE, FLAG_OUTPUT_NONFINITE
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+class StateDictKeyError(KeyError):
+    """A requested key is missing (reference streaming.py:181-186): the executor skips the key."""
+
+    def __init__(self, key: str):
+        super().__init__(key)
+
+
+class NonFiniteStateDictKeyError(StateDictKeyError):
+    """A requested key contains non-finite values (reference streaming.py:189-194)."""
+
+    def __init__(self, key):
+        super().__init__(f"key '{key}' contains non-finite values")
+
+
+# ------------------------------------------------------------------ plumbing
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _resolve(x, key):
+    """StateDict-typed parameter: a tensor, or a mapping indexed by ``key`` (merging.py:579-589)."""
+    if isinstance(x, Mapping):
+        try:
+            return x[key]
+        except KeyError as e:
+            raise StateDictKeyError(key) from e
+    return x
+
+
+def _check_inputs(tensors: Sequence[torch.Tensor], what: str) -> None:
+    """Host-side validation of everything the kernels and their grids assume."""
+    t0 = tensors[0]
+    for i, t in enumerate(tensors):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{what}: argument {i} is {type(t).__name__}, expected a torch.Tensor")
+        if not t.is_cuda:
+            raise RuntimeError(f"{what}: argument {i} is on {t.device}; the MI355X backend has no CPU path")
+        if t.dtype not in _DT:
+            raise TypeError(f"{what}: unsupported dtype {t.dtype} (float32, float16, bfloat16)")
+        if t.shape != t0.shape or t.dtype != t0.dtype or t.device != t0.device:
+            raise ValueError(f"{what}: argument {i} has shape {tuple(t.shape)} / {t.dtype} / {t.device}, "
+                             f"expected {tuple(t0.shape)} / {t0.dtype} / {t0.device}")
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _alpha(alpha) -> float:
+    """Scalar hyper-parameters arrive as 0-d fp32 tensors in the reference (merging.py:632-633)."""
+    if isinstance(alpha, torch.Tensor):
+        if alpha.numel() != 1:
+            raise NotImplementedError("per-element alpha tensors are outside the MI355X hot path (SURVEY §8 a7)")
+        alpha = alpha.item()
+    return float(torch.tensor(float(alpha), dtype=torch.float32).item())
+
+
+class _Flags:
+    """Device flag word for one call; raises like omit_non_finite / warns like _track_output."""
+
+    def __init__(self, device, external: Optional[torch.Tensor], check: bool):
+        self.external = external
+        self.check = check and external is None
+        self.t = external if external is not None else (torch.zeros(1, dtype=torch.int32, device=device) if check else None)
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.t.data_ptr()) if self.t is not None else None
+
+    def finish(self, key):
+        if self.check:
+            bits = int(self.t.item())
+            if bits & FLAG_INPUT_NONFINITE:
+                raise NonFiniteStateDictKeyError(key)
+
+
+def _out(like: torch.Tensor, out_dtype) -> torch.Tensor:
+    return torch.empty(like.shape, dtype=out_dtype or torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------ logistics.py
+def cast(a, dtype=torch.float32, *, key=None, flags=None, check_finite=True) -> torch.Tensor:
+    """cast (logistics.py:38-53) fused with omit_non_finite (logistics.py:132-142)."""
+    a = _c(_resolve(a, key))
+    _check_inputs([a], "cast")
+    out = _out(a, dtype)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(_lib.lib().mecha_cast(a.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype], _DT[out.dtype], fl.ptr, _stream()), "mecha_cast")
+    fl.finish(key)
+    return out
+
+
+def omit_non_finite(a, *, key=None) -> torch.Tensor:
+    """omit_non_finite (logistics.py:132-142): raises NonFiniteStateDictKeyError, else returns ``a``."""
+    a = _resolve(a, key)
+    ac = _c(a)
+    _check_inputs([ac], "omit_non_finite")
+    fl = _Flags(a.device, None, True)
+    _lib.check(_lib.lib().mecha_cast(ac.data_ptr(), None, ac.numel(), _DT[ac.dtype], _DT[ac.dtype], fl.ptr, _stream()), "mecha_cast")
+    fl.finish(key)
+    return a
+
+
+# ------------------------------------------------------------------ linear.py
+def weighted_sum(a, b, alpha=0.5, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
+    """weighted_sum (linear.py:7-23).  alpha == 0 returns a, alpha == 1 returns b, without touching the other."""
+    al = _alpha(alpha)
+    if math.isclose(al, 0.0):
+        return cast(a, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
+    if math.isclose(al, 1.0):
+        return cast(b, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
+    a, b = _c(_resolve(a, key)), _c(_resolve(b, key))
+    _check_inputs([a, b], "weighted_sum")
+    out = _out(a, out_dtype)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(_lib.lib().mecha_weighted_sum(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype], _DT[out.dtype],
+                                             al, fl.ptr, _stream()), "mecha_weighted_sum")
+    fl.finish(key)
+    return out
+
+
+def n_average(*models, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
+    """n_average (linear.py:26-40)."""
+    assert models
+    ms = [_c(_resolve(m, key)) for m in models]
+    _check_inputs(ms, "n_average")
+    if len(ms) > _lib.MAX_MODELS:
+        raise ValueError(f"n_average: at most {_lib.MAX_MODELS} models per call")
+    out = _out(ms[0], out_dtype)
+    fl = _Flags(ms[0].device, flags, check_finite)
+    _lib.check(_lib.lib().mecha_n_average(_lib.ptr_array([m.data_ptr() for m in ms]), len(ms), out.data_ptr(), out.numel(),
+                                          _DT[ms[0].dtype], _DT[out.dtype], fl.ptr, _stream()), "mecha_n_average")
+    fl.finish(key)
+    return out
+
+
+def add_difference(a, b, alpha=1.0, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
+    """add_difference (linear.py:64-76): a.addcmul(b, alpha); alpha == 0 returns a."""
+    al = _alpha(alpha)
+    if math.isclose(al, 0.0):
+        return cast(a, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
+    b = _c(_resolve(b, key))      # b first, like the reference (linear.py:75)
+    a = _c(_resolve(a, key))
+    _check_inputs([a, b], "add_difference")
+    out = _out(a, out_dtype)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(_lib.lib().mecha_add_difference(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype], _DT[out.dtype],
+                                               al, fl.ptr, _stream()), "mecha_add_difference")
+    fl.finish(key)
+    return out
+
+
+def subtract(a, b, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
+    """subtract (linear.py:96-101)."""
+    a, b = _c(_resolve(a, key)), _c(_resolve(b, key))
+    _check_inputs([a, b], "subtract")
+    out = _out(a, out_dtype)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(_lib.lib().mecha_subtract(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype], _DT[out.dtype],
+                                         fl.ptr, _stream()), "mecha_subtract")
+    fl.finish(key)
+    return out
+
+
+def scale(a, alpha=1.0, *, key=None, out_dtype=None, flags=None, check_finite=True):
+    """scale (linear.py:79-93); alpha == 0 returns python 0.0 like the reference."""
+    al = _alpha(alpha)
+    if math.isclose(al, 0.0):
+        return 0.0
+    a = _c(_resolve(a, key))
+    _check_inputs([a], "scale")
+    out = _out(a, out_dtype)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(_lib.lib().mecha_scale(a.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype], _DT[out.dtype], al, fl.ptr, _stream()),
+               "mecha_scale")
+    fl.finish(key)
+    return out
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def slerp(a, b, alpha=0.5, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
+    """slerp (linear.py:43-61)."""
+    a, b = _c(_resolve(a, key)), _c(_resolve(b, key))
+    _check_inputs([a, b], "slerp")
+    out = _out(a, out_dtype)
+    L = _lib.lib()
+    ws = _workspace(L.mecha_reduce_workspace_bytes(a.numel()), a.device)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(L.mecha_slerp(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype], _DT[out.dtype], _alpha(alpha),
+                             ws.data_ptr(), ws.numel(), fl.ptr, _stream()), "mecha_slerp")
+    fl.finish(key)
+    return out
+
+
+def perpendicular_component(a, b, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
+    """perpendicular_component (linear.py:104-113)."""
+    a, b = _c(_resolve(a, key)), _c(_resolve(b, key))
+    _check_inputs([a, b], "perpendicular_component")
+    out = _out(a, out_dtype)
+    L = _lib.lib()
+    ws = _workspace(L.mecha_reduce_workspace_bytes(a.numel()), a.device)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(L.mecha_perpendicular_component(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype], _DT[out.dtype],
+                                               ws.data_ptr(), ws.numel(), fl.ptr, _stream()), "mecha_perpendicular_component")
+    fl.finish(key)
+    return out
+
+
+def add_perpendicular(a, b, c, alpha=1.0, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
+    """The recipe of wrappers.py:42-64, fused: a + alpha * perpendicular_component(a - c, b - c)."""
+    al = _alpha(alpha)
+    if math.isclose(al, 0.0):
+        return cast(a, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
+    a, b, c = _c(_resolve(a, key)), _c(_resolve(b, key)), _c(_resolve(c, key))
+    _check_inputs([a, b, c], "add_perpendicular")
+    out = _out(a, out_dtype)
+    L = _lib.lib()
+    ws = _workspace(L.mecha_reduce_workspace_bytes(a.numel()), a.device)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(L.mecha_add_perpendicular(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype],
+                                         _DT[out.dtype], al, ws.data_ptr(), ws.numel(), fl.ptr, _stream()), "mecha_add_perpendicular")
+    fl.finish(key)
+    return out
+
+
+# ------------------------------------------------------------------ ties.py
+def _thresholds(n_models: int, device, want: bool):
+    return torch.empty(n_models, dtype=torch.float32, device=device) if want else None
+
+
+def ties_sum(*models, k: float = 1.0, vote_sgn: bool = False, out_dtype=None, flags=None, check_finite=True,
+             return_thresholds: bool = False):
+    """ties_sum (ties.py:98-125).  No models -> python 0; empty tensor -> returned as is."""
+    if not models:
+        return 0
+    if models[0].numel() == 0:
+        return models[0]
+    ms = [_c(m) for m in models]
+    _check_inputs(ms, "ties_sum")
+    if len(ms) > _lib.MAX_MODELS:
+        raise ValueError(f"ties_sum: at most {_lib.MAX_MODELS} deltas per call")
+    out = _out(ms[0], out_dtype)
+    L = _lib.lib()
+    ws = _workspace(L.mecha_ties_workspace_bytes(len(ms), out.numel()), out.device)
+    thr = _thresholds(len(ms), out.device, return_thresholds)
+    fl = _Flags(out.device, flags, check_finite)
+    _lib.check(L.mecha_ties_sum(_lib.ptr_array([m.data_ptr() for m in ms]), len(ms), out.data_ptr(), out.numel(), _DT[ms[0].dtype],
+                                _DT[out.dtype], float(k), int(bool(vote_sgn)), thr.data_ptr() if thr is not None else None,
+                                ws.data_ptr(), ws.numel(), fl.ptr, _stream()), "mecha_ties_sum")
+    fl.finish(None)
+    return (out, thr) if return_thresholds else out
+
+
+def add_difference_ties(base, *models, k: float = 0.2, alpha=1.0, vote_sgn: bool = False, key=None, out_dtype=None,
+                        flags=None, check_finite=True, return_thresholds: bool = False):
+    """The recipe of wrappers.py:70-94 fused into one pipeline:
+    add_difference(base, ties_sum(m_0 - base, ..., k), alpha).  Reads bf16/fp16 inputs directly."""
+    al = _alpha(alpha)
+    if math.isclose(al, 0.0) or not models:
+        r = cast(base, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
+        return (r, None) if return_thresholds else r
+    ts = [_c(_resolve(t, key)) for t in (base, *models)]
+    _check_inputs(ts, "add_difference_ties")
+    if ts[0].numel() == 0:
+        r = _out(ts[0], out_dtype)
+        return (r, None) if return_thresholds else r
+    out = _out(ts[0], out_dtype)
+    L = _lib.lib()
+    n = len(ts) - 1
+    ws = _workspace(L.mecha_ties_workspace_bytes(n, out.numel()), out.device)
+    thr = _thresholds(n, out.device, return_thresholds)
+    fl = _Flags(out.device, flags, check_finite)
+    _lib.check(L.mecha_add_difference_ties(ts[0].data_ptr(), _lib.ptr_array([m.data_ptr() for m in ts[1:]]), n, out.data_ptr(),
+                                           out.numel(), _DT[ts[0].dtype], _DT[out.dtype], float(k), al, int(bool(vote_sgn)),
+                                           thr.data_ptr() if thr is not None else None, ws.data_ptr(), ws.numel(), fl.ptr, _stream()),
+               "mecha_add_difference_ties")
+    fl.finish(key)
+    return (out, thr) if return_thresholds else out
+
+
+def dare_draw_masks(seed: int, probability: float, n_models: int, numel: int, device) -> torch.Tensor:
+    """The keep masks the reference draws with torch's CPU generator (ties.py:29-33, :63-64), bit-packed,
+    drawn on the host by libmecha_hip and uploaded: int32 [n_models, ceil(numel / 32)]."""
+    words = (numel + 31) // 32
+    host = torch.empty((n_models, words), dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.empty((n_models, words), dtype=torch.int32)
+    _lib.check(_lib.lib().mecha_dare_draw_masks_host(int(seed) & 0xFFFFFFFFFFFFFFFF, float(probability), n_models, numel, host.data_ptr()),
+               "mecha_dare_draw_masks_host")
+    return host.to(device, non_blocking=False)
+
+
+def ties_sum_with_dropout(*deltas, probability=0.9, della_eps: float = 0.0, rescale: bool = True, k: float = 0.2,
+                          vote_sgn: bool = False, apply_stock: bool = False, cos_eps: float = 1e-6, apply_median: bool = False,
+                          eps: float = 1e-6, maxiter: int = 100, ftol: float = 1e-20, seed: Optional[int] = None,
+                          out_dtype=None, flags=None, check_finite=True, keep_bits: Optional[torch.Tensor] = None):
+    """DARE: ties_sum_with_dropout (ties.py:10-50).  In scope on MI355X: della_eps == 0, apply_median == False and
+    apply_stock == True (t = 1, ties.py:90 -- note the reference APPLIES the model-stock factor when apply_stock is
+    False); anything else raises NotImplementedError.  Masks follow the reference's CPU generator stream for
+    seed >= 0 (pass ``keep_bits`` to supply your own)."""
+    p = _alpha(probability)
+    if not deltas or math.isclose(p, 1.0):
+        return 0
+    if not math.isclose(della_eps, 0.0) or apply_median or not apply_stock:
+        raise NotImplementedError("MI355X DARE path covers della_eps == 0, apply_median == False, apply_stock == True "
+                                  "(SURVEY §8 a15 / §8f-4); other settings stay on the reference")
+    ds = [_c(d) for d in deltas]
+    _check_inputs(ds, "ties_sum_with_dropout")
+    if ds[0].numel() == 0:
+        return ds[0]
+    n, numel = len(ds), ds[0].numel()
+    if keep_bits is None:
+        if seed is None or seed < 0:
+            seed = int(torch.seed() & 0xFFFFFFFF)          # unseeded generator (ties.py:29-31)
+        keep_bits = dare_draw_masks(seed, p, n, numel, ds[0].device)
+    if keep_bits.dtype != torch.int32 or tuple(keep_bits.shape) != (n, (numel + 31) // 32) or keep_bits.device != ds[0].device:
+        raise ValueError("keep_bits must be int32 [n_models, ceil(numel/32)] on the deltas' device")
+    keep_bits = _c(keep_bits)
+    out = _out(ds[0], out_dtype)
+    L = _lib.lib()
+    ws = _workspace(L.mecha_ties_workspace_bytes(n, numel), out.device)
+    fl = _Flags(out.device, flags, check_finite)
+    _lib.check(L.mecha_ties_sum_with_dropout(_lib.ptr_array([d.data_ptr() for d in ds]), n, keep_bits.data_ptr(), out.data_ptr(), numel,
+                                             _DT[ds[0].dtype], _DT[out.dtype], float(k), int(bool(vote_sgn)), p, int(bool(rescale)),
+                                             None, ws.data_ptr(), ws.numel(), fl.ptr, _stream()), "mecha_ties_sum_with_dropout")
+    fl.finish(None)
+    return out
