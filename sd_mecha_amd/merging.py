@@ -1,0 +1,518 @@
+"""The key scheduler: ``merge(recipe, ...)`` for the MI355X backend.
+
+Replaces the executor of ``/root/reference/sd_mecha/merging.py`` (merge :34-239, KeyMergeVisitor :374-482,
+CastInputDicts :639-697, _track_output :292-317) for the hot path:
+
+* the reference submits ONE future per key to <= 4 threads (:171-179, :223-229); here the keys of this rank's
+  stripe are packed into *waves* -- per-model arenas with identical offsets (arena.py) -- and every wave is
+  merged by one batched launch sequence through the C ABI;
+* inputs move mmap -> pinned staging -> ``hipMemcpyAsync`` on a copy stream, outputs come back on a third
+  stream, double-buffered so H2D(w+1), compute(w) and D2H(w-1) overlap;
+* the per-input ``cast`` + ``omit_non_finite`` nodes the reference wraps around every model (:673-681) and the
+  ``check_finite_output`` test (:297-308) are fused into the kernels and come back as one flag word per key;
+* recipes the fuser does not recognise (user ``@merge_method`` bodies, out-of-scope builtins) are evaluated key by
+  key with the same Python bodies on ROCm tensors;
+* with ``torch.distributed`` initialised, keys are dealt over ranks (LPT by size) and every rank writes its
+  own region of the one output file -- no data-path collective.
+
+Results-changing defaults are the reference's: merge_dtype fp32, output_dtype fp16, omit_non_finite_inputs,
+check_finite_output (:112-146).
+"""
+from __future__ import annotations
+
+import logging
+import math
+import pathlib
+import threading
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Mapping, MutableMapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import merge_methods as mm
+from .arena import ArenaLayout, plan_arena, shard_keys_lpt
+from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError
+from .recipe_nodes import LiteralRecipeNode, MergeRecipeNode, ModelRecipeNode, RecipeNode, serialize, value_to_node
+from .streaming import DTYPE_REVERSE_MAPPING, InSafetensorsDict, OutSafetensorsDict, TensorMetadata, compact_holes
+
+_DT_CODE = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+log = logging.getLogger("sd_mecha_amd")
+
+
+# ================================================================== graph analysis
+@dataclass
+class FusedPlan:
+    """A recipe the batched kernels cover end to end."""
+    kind: str                                   # "wsum" | "navg" | "ties"
+    models: List[ModelRecipeNode]               # inputs in kernel order (ties: base first)
+    params: Dict[str, Any] = field(default_factory=dict)
+    fallback: Optional[ModelRecipeNode] = None  # `| model`: value of a key whose merge was skipped
+
+
+def _scalar(node: RecipeNode, default=None):
+    if node is None:
+        return default
+    if isinstance(node, LiteralRecipeNode) and isinstance(node.value, (int, float)) and not isinstance(node.value, bool):
+        return float(node.value)
+    return None
+
+
+def _bound(node: MergeRecipeNode) -> Dict[str, RecipeNode]:
+    """Bind positional/keyword nodes to parameter names of the method body."""
+    sig = node.merge_method.signature
+    params = [p for p in sig.parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+    out = {}
+    for p, a in zip(params, node.args):
+        out[p.name] = a
+    out.update(node.kwargs)
+    return out
+
+
+def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
+    """Recognise the node chains of SURVEY.md §3.2-3.3 (wrappers.py shapes); None = evaluate generically."""
+    fallback = None
+    if isinstance(recipe, MergeRecipeNode) and recipe.merge_method.identifier == "fallback":
+        a, d = recipe.args[0], recipe.args[1] if len(recipe.args) > 1 else recipe.kwargs.get("default")
+        if isinstance(d, ModelRecipeNode):
+            recipe, fallback = a, d
+    if not isinstance(recipe, MergeRecipeNode):
+        return None
+    ident = recipe.merge_method.identifier
+    if ident == "weighted_sum":
+        b = _bound(recipe)
+        alpha = _scalar(b.get("alpha"), 0.5) if "alpha" in b else 0.5
+        if isinstance(b.get("a"), ModelRecipeNode) and isinstance(b.get("b"), ModelRecipeNode) and alpha is not None:
+            return FusedPlan("wsum", [b["a"], b["b"]], {"alpha": alpha}, fallback)
+    if ident == "n_average":
+        if recipe.args and all(isinstance(a, ModelRecipeNode) for a in recipe.args) and not recipe.kwargs and len(recipe.args) <= _lib.MAX_MODELS:
+            return FusedPlan("navg", list(recipe.args), {}, fallback)
+    if ident == "add_difference":
+        b = _bound(recipe)
+        alpha = _scalar(b.get("alpha"), 1.0) if "alpha" in b else 1.0
+        base, t = b.get("a"), b.get("b")
+        if isinstance(base, ModelRecipeNode) and alpha is not None and isinstance(t, MergeRecipeNode) and t.merge_method.identifier == "ties_sum":
+            k = _scalar(t.kwargs.get("k"), 1.0) if "k" in t.kwargs else 1.0
+            vote = t.kwargs.get("vote_sgn")
+            vote = bool(vote.value) if isinstance(vote, LiteralRecipeNode) else False
+            models = []
+            for d in t.args:
+                if not (isinstance(d, MergeRecipeNode) and d.merge_method.identifier == "subtract" and len(d.args) == 2
+                        and isinstance(d.args[0], ModelRecipeNode) and d.args[1] is base):
+                    return None
+                models.append(d.args[0])
+            if k is not None and models and len(models) < _lib.MAX_MODELS and not math.isclose(alpha, 0.0):
+                return FusedPlan("ties", [base] + models, {"k": k, "alpha": alpha, "vote_sgn": vote}, fallback)
+    return None
+
+
+def collect_models(recipe: RecipeNode) -> List[ModelRecipeNode]:
+    seen, out = set(), []
+
+    def walk(n):
+        if isinstance(n, ModelRecipeNode):
+            if id(n) not in seen:
+                seen.add(id(n))
+                out.append(n)
+        elif isinstance(n, MergeRecipeNode):
+            for a in n.args:
+                walk(a)
+            for a in n.kwargs.values():
+                walk(a)
+    walk(recipe)
+    return out
+
+
+# ================================================================== compute backends
+class HipBackend:
+    """libmecha_hip.so on the current ROCm device.  The only product backend: no CPU path."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"merge_device={device!r}: the MI355X backend runs on a ROCm device only (there is no CPU path)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device is visible; the MI355X backend has no CPU fallback")
+        self.lib = _lib.lib()
+        self.methods = mm
+
+    def stream(self):
+        return torch.cuda.Stream(device=self.device)
+
+    def run_fused(self, plan: FusedPlan, arenas: Sequence[torch.Tensor], out: torch.Tensor, layout: ArenaLayout,
+                  segs_dev: torch.Tensor, segs_host, flags: torch.Tensor, workspace: Optional[torch.Tensor]) -> None:
+        import ctypes
+        L = self.lib
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        in_dt, out_dt, n = _DT_CODE[arenas[0].dtype], _DT_CODE[out.dtype], len(layout.keys)
+        if plan.kind == "wsum":
+            st = L.mecha_batched_weighted_sum(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(), segs_dev.data_ptr(), n,
+                                              layout.total_elems, in_dt, out_dt, plan.params["alpha"], flags.data_ptr(), stream)
+        elif plan.kind == "navg":
+            st = L.mecha_batched_n_average(_lib.ptr_array([a.data_ptr() for a in arenas]), len(arenas), out.data_ptr(), segs_dev.data_ptr(),
+                                           n, layout.total_elems, in_dt, out_dt, flags.data_ptr(), stream)
+        elif plan.kind == "ties":
+            st = L.mecha_batched_add_difference_ties(
+                arenas[0].data_ptr(), _lib.ptr_array([a.data_ptr() for a in arenas[1:]]), len(arenas) - 1, out.data_ptr(),
+                segs_dev.data_ptr(), ctypes.addressof(segs_host), n, layout.total_elems, in_dt, out_dt, plan.params["k"],
+                plan.params["alpha"], int(plan.params["vote_sgn"]), None, workspace.data_ptr(), workspace.numel(), flags.data_ptr(), stream)
+        else:
+            raise ValueError(plan.kind)
+        _lib.check(st, f"batched {plan.kind}")
+
+    def workspace_bytes(self, plan: FusedPlan, layout: ArenaLayout) -> int:
+        if plan.kind == "ties":
+            return int(self.lib.mecha_batched_ties_workspace_bytes(len(plan.models) - 1, len(layout.keys), layout.total_elems))
+        return 0
+
+
+# ================================================================== the executor
+@dataclass
+class _Wave:
+    keys: List[str]
+    layout: ArenaLayout
+
+
+def _plan_waves(items: Sequence[Tuple[str, int]], wave_elems: int) -> List[_Wave]:
+    """Pack keys (file order) into waves of at most `wave_elems` elements per model; a key larger than the window
+    gets a wave of its own (the reference likewise grows its buffer to the tensor, streaming.py:154-158)."""
+    waves, cur, cur_elems = [], [], 0
+    for key, n in items:
+        if cur and cur_elems + n > wave_elems:
+            waves.append(cur)
+            cur, cur_elems = [], 0
+        cur.append((key, n))
+        cur_elems += (n + 127) // 128 * 128
+    if cur:
+        waves.append(cur)
+    return [_Wave([k for k, _ in w], plan_arena(w)) for w in waves]
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), dist
+    return 0, 1, None
+
+
+def merge(
+    recipe,
+    *,
+    fallback_model=None,
+    merge_device: Optional[str] = "cuda",
+    merge_dtype: torch.dtype = torch.float32,
+    output_device: Optional[str] = "cpu",
+    output_dtype: torch.dtype = torch.float16,
+    total_buffer_size: int = 2 ** 31,
+    check_finite_output: bool = True,
+    omit_non_finite_inputs: bool = True,
+    strict_mandatory_keys: bool = False,
+    output=None,
+    backend=None,
+) -> Optional[MutableMapping[str, torch.Tensor]]:
+    """Materialise a state dict from a recipe graph (signature subset of reference merging.py:34-54).
+
+    ``output``: a ``.safetensors`` path, a dict-like, or None (a new dict is returned).  ``total_buffer_size`` is the
+    byte budget of the pinned staging buffers (the reference's 2**28 read window scaled to a 288 GB device).
+    Under ``torch.distributed`` every rank merges its own stripe of keys; with a file output all ranks fill the same
+    file, with a dict output each rank returns its stripe."""
+    if merge_dtype != torch.float32:
+        raise NotImplementedError("the MI355X kernels compute in float32 (the reference default merge_dtype)")
+    if not omit_non_finite_inputs:
+        raise NotImplementedError("omit_non_finite_inputs=False is not supported: the finite check is fused into the kernels")
+    recipe = value_to_node(recipe)
+    if fallback_model is not None:
+        recipe = recipe | value_to_node(fallback_model)                      # merging.py:154-155
+    backend = backend or HipBackend(merge_device)
+    rank, world, dist = _dist_info()
+
+    models = collect_models(recipe)
+    if not models:
+        raise ValueError("the recipe has no model inputs")
+    readers = {id(m): InSafetensorsDict(m.path) for m in models}
+    try:
+        plan = fuse(recipe)
+        recipe_text = serialize(recipe)
+        # structural key inference: keys every input of the merge holds with one shape (minimal)
+        first = readers[id(models[0])]
+        merge_inputs = plan.models if plan is not None else models
+        items, header = [], {}
+        for key, meta in first.metadata():
+            ok = all(key in readers[id(m)] and readers[id(m)].meta(key).shape == meta.shape for m in merge_inputs)
+            if ok:
+                items.append((key, meta.numel()))
+                header[key] = TensorMetadata(meta.shape, output_dtype)
+        my_items = shard_keys_lpt(items, world)[rank] if world > 1 else items
+        order = {k: i for i, (k, _) in enumerate(items)}
+        my_items.sort(key=lambda kv: order[kv[0]])
+
+        to_file = isinstance(output, (str, pathlib.Path))
+        sink: Any
+        if to_file:
+            out_path = pathlib.Path(output)
+            esz = DTYPE_REVERSE_MAPPING[output_dtype][1]
+            sizes = [sum(n for _, n in shard) * esz for shard in (shard_keys_lpt(items, world) if world > 1 else [items])]
+            region_start = sum(sizes[:rank])
+            if world > 1:
+                if rank == 0:
+                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=True, region_start=region_start)
+                dist.barrier()
+                if rank != 0:
+                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=False, region_start=region_start)
+            else:
+                sink = OutSafetensorsDict(out_path, header, recipe_text)
+        else:
+            sink = output if output is not None else {}
+            sink["__metadata__"] = {"mecha_recipe": recipe_text}              # merging.py:287-288
+
+        skipped: List[str] = []
+        if plan is not None and _fusable_dtypes(plan, readers, my_items):
+            _run_fused(plan, backend, readers, my_items, header, sink, to_file, output_device, output_dtype,
+                       total_buffer_size, check_finite_output, skipped)
+        else:
+            _run_generic(recipe, backend, readers, my_items, header, sink, to_file, output_device, output_dtype,
+                         check_finite_output, strict_mandatory_keys, skipped)
+        for k in skipped:
+            log.debug("Skipping key: %s", k)
+
+        if to_file:
+            if world > 1:
+                gathered = [None] * world if rank == 0 else None
+                dist.gather_object((sink.entries, skipped), gathered, dst=0)
+                if rank == 0:
+                    extra = {}
+                    any_skipped = False
+                    for r, (entries, sk) in enumerate(gathered):
+                        any_skipped |= bool(sk)
+                        if r != 0:
+                            extra.update(entries)
+                    sink.close(extra_entries=extra)
+                    if any_skipped:
+                        compact_holes(out_path)
+                else:
+                    sink.close(write_header=False)
+                dist.barrier()
+            else:
+                sink.close()
+                if skipped:
+                    compact_holes(out_path)
+            return None
+        return sink
+    finally:
+        for r in readers.values():
+            r.close()
+
+
+def _fusable_dtypes(plan: FusedPlan, readers, items) -> bool:
+    """The batched kernels read one storage dtype for every input; mixed or integer checkpoints go generic."""
+    if not items:
+        return True
+    dts = set()
+    for key, _ in items:
+        for m in plan.models:
+            dts.add(readers[id(m)].meta(key).dtype)
+    return len(dts) == 1 and next(iter(dts)) in _DT_CODE
+
+
+# ------------------------------------------------------------------ fused (batched) path
+def _run_fused(plan, backend, readers, items, header, sink, to_file, output_device, output_dtype, total_buffer_size,
+               check_finite_output, skipped):
+    dev = backend.device
+    is_cuda = dev.type == "cuda"
+    in_dtype = readers[id(plan.models[0])].meta(items[0][0]).dtype if items else torch.float16
+    n_models = len(plan.models)
+    in_esz, out_esz = DTYPE_REVERSE_MAPPING[in_dtype][1], DTYPE_REVERSE_MAPPING[output_dtype][1]
+    # two buffer sets (double buffering), each holding n_models inputs + 1 output
+    per_set = max(total_buffer_size // 2, 1 << 20)
+    wave_elems = max(per_set // (n_models * in_esz + out_esz), 1024)
+    waves = _plan_waves(items, wave_elems)
+    if not waves:
+        return
+    cap = max(w.layout.total_elems for w in waves)
+
+    def alloc_set():
+        pin = dict(pin_memory=True) if is_cuda else {}
+        return {
+            "h_in": [torch.empty(cap, dtype=in_dtype, **pin) for _ in range(n_models)],
+            "h_out": torch.empty(cap, dtype=output_dtype, **pin),
+            "d_in": [torch.empty(cap, dtype=in_dtype, device=dev) for _ in range(n_models)],
+            "d_out": torch.empty(cap, dtype=output_dtype, device=dev),
+            "flags": None, "h_flags": None, "ev_h2d": None, "ev_comp": None, "ev_d2h": None, "wave": None,
+        }
+    sets = [alloc_set(), alloc_set()] if len(waves) > 1 else [alloc_set()]
+    s_copy_in = backend.stream() if is_cuda else None
+    s_comp = backend.stream() if is_cuda else None
+    s_copy_out = backend.stream() if is_cuda else None
+
+    def stage(bs, wave: _Wave):
+        """mmap -> pinned staging: one memcpy per (model, key) into the arena offsets."""
+        L = wave.layout
+        esz = in_esz
+
+        def fill(mi):
+            reader = readers[id(plan.models[mi])]
+            dst = bs["h_in"][mi].view(torch.uint8).numpy()
+            for key, off, n in zip(L.keys, L.offsets, L.numels):
+                dst[off * esz:(off + n) * esz] = np.frombuffer(reader.raw(key), dtype=np.uint8)
+                pad_end = (off + n + 127) // 128 * 128
+                dst[(off + n) * esz:min(pad_end, cap) * esz] = 0               # gaps stay finite
+        threads = [threading.Thread(target=fill, args=(mi,)) for mi in range(n_models)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+
+    def launch(bs, wave: _Wave):
+        L = wave.layout
+        bs["wave"] = wave
+        segs_host = L.host_segments()
+        bs["segs_host"] = segs_host
+        ctx_in = torch.cuda.stream(s_copy_in) if is_cuda else _null()
+        with ctx_in:
+            for mi in range(n_models):
+                bs["d_in"][mi][:L.total_elems].copy_(bs["h_in"][mi][:L.total_elems], non_blocking=True)
+            segs_dev = L.device_segments(dev)
+            if is_cuda:
+                bs["ev_h2d"] = torch.cuda.Event()
+                bs["ev_h2d"].record(s_copy_in)
+        ctx = torch.cuda.stream(s_comp) if is_cuda else _null()
+        with ctx:
+            if is_cuda:
+                s_comp.wait_event(bs["ev_h2d"])
+            flags = torch.zeros(len(L.keys), dtype=torch.int32, device=dev)
+            nbytes = backend.workspace_bytes(plan, L)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if nbytes else None
+            backend.run_fused(plan, [a[:L.total_elems] for a in bs["d_in"]], bs["d_out"][:L.total_elems], L, segs_dev, segs_host, flags, ws)
+            bs["flags"], bs["ws"], bs["segs_dev"] = flags, ws, segs_dev
+            if is_cuda:
+                bs["ev_comp"] = torch.cuda.Event()
+                bs["ev_comp"].record(s_comp)
+        ctx_out = torch.cuda.stream(s_copy_out) if is_cuda else _null()
+        with ctx_out:
+            if is_cuda:
+                s_copy_out.wait_event(bs["ev_comp"])
+            bs["h_out"][:L.total_elems].copy_(bs["d_out"][:L.total_elems], non_blocking=True)
+            bs["h_flags"] = flags.to("cpu", non_blocking=False) if not is_cuda else torch.empty(len(L.keys), dtype=torch.int32, pin_memory=True)
+            if is_cuda:
+                bs["h_flags"].copy_(flags, non_blocking=True)
+                bs["ev_d2h"] = torch.cuda.Event()
+                bs["ev_d2h"].record(s_copy_out)
+
+    def drain(bs):
+        """Wait for the wave's D2H, then hand every key to the sink (file region or dict)."""
+        wave = bs["wave"]
+        if wave is None:
+            return
+        if is_cuda:
+            bs["ev_d2h"].synchronize()
+        L = wave.layout
+        fl = bs["h_flags"].numpy()
+        out_bytes = bs["h_out"].view(torch.uint8).numpy()
+        for i, (key, off, n) in enumerate(zip(L.keys, L.offsets, L.numels)):
+            meta = header[key]
+            if fl[i] & _lib.FLAG_INPUT_NONFINITE:
+                if not _write_fallback(plan, readers, key, meta, sink, to_file, output_device, output_dtype):
+                    skipped.append(key)
+                continue
+            if (fl[i] & _lib.FLAG_OUTPUT_NONFINITE) and check_finite_output:
+                log.warning("There are non finite values in key '%s': %s", key, meta)     # merging.py:303-308
+            if to_file:
+                sink.put(key, meta, out_bytes[off * out_esz:(off + n) * out_esz])
+            else:
+                t = bs["h_out"][off:off + n].clone().view(meta.shape)
+                sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t
+        bs["wave"] = None
+
+    # software pipeline over waves: stage(w+1) on the host overlaps H2D/compute/D2H of w
+    stage(sets[0], waves[0])
+    for w, wave in enumerate(waves):
+        bs = sets[w % len(sets)]
+        launch(bs, wave)
+        if w + 1 < len(waves):
+            nxt = sets[(w + 1) % len(sets)]
+            drain(nxt)                      # the set we are about to refill must have been written out
+            stage(nxt, waves[w + 1])
+    for bs in sets:
+        drain(bs)
+    if is_cuda:
+        torch.cuda.synchronize(dev)
+
+
+def _write_fallback(plan, readers, key, meta, sink, to_file, output_device, output_dtype) -> bool:
+    """`recipe | model` (logistics.py:12-35): a key whose merge was skipped comes from the fallback model, cast to the
+    output dtype.  Returns False when there is no usable fallback (the key is then omitted, merging.py:312-316)."""
+    if plan.fallback is None:
+        return False
+    reader = readers[id(plan.fallback)]
+    if key not in reader:
+        return False
+    t = reader[key]
+    if t.is_floating_point() and not bool(torch.isfinite(t.float()).all()):
+        return False                                                          # the fallback's own omit_non_finite
+    t = t.to(output_dtype)
+    if to_file:
+        sink.put(key, meta, t.contiguous().view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+    else:
+        sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t
+    return True
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+# ------------------------------------------------------------------ generic (per key) path
+def _run_generic(recipe, backend, readers, items, header, sink, to_file, output_device, output_dtype, check_finite_output,
+                 strict_mandatory_keys, skipped):
+    """KeyMergeVisitor (merging.py:374-482) for graphs the fuser does not cover: every model value is uploaded,
+    cast to fp32 with the fused finite check, and the method bodies run per key on device tensors."""
+    dev = backend.device
+    methods = backend.methods
+
+    def evaluate(node: RecipeNode, key: str):
+        if isinstance(node, ModelRecipeNode):
+            reader = readers[id(node)]
+            if key not in reader:
+                raise StateDictKeyError(key)
+            t = reader[key].to(dev)
+            if t.dtype in _DT_CODE and t.numel():
+                return methods.cast(t, torch.float32, key=key)                 # cast + omit_non_finite (merging.py:673-681)
+            return t.to(torch.float32)
+        if isinstance(node, LiteralRecipeNode):
+            return node.value
+        if isinstance(node, MergeRecipeNode):
+            if node.merge_method.identifier == "fallback":
+                for cand in node.args:
+                    try:
+                        return evaluate(cand, key)
+                    except StateDictKeyError:
+                        continue
+                raise StateDictKeyError(key)
+            args = [evaluate(a, key) for a in node.args]
+            kwargs = {k: evaluate(v, key) for k, v in node.kwargs.items()}
+            return node.merge_method.merge_key(args, kwargs, key)
+        raise TypeError(type(node))
+
+    for key, _ in items:
+        meta = header[key]
+        try:
+            res = evaluate(recipe, key)
+        except StateDictKeyError as e:
+            if strict_mandatory_keys:
+                raise RuntimeError(f"Could not merge mandatory key: {e}") from e
+            skipped.append(key)
+            continue
+        if not isinstance(res, torch.Tensor):
+            res = torch.full(meta.shape, float(res), dtype=torch.float32, device=dev)
+        if check_finite_output and res.numel() and not bool(torch.isfinite(res).all()):
+            log.warning("There are non finite values in key '%s': %s", key, meta)
+        res = res.to(output_dtype).reshape(meta.shape)
+        if to_file:
+            sink[key] = res
+        else:
+            sink[key] = res.to(output_device) if output_device is not None else res

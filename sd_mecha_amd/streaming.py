@@ -1,0 +1,265 @@
+"""safetensors reader / writer of the MI355X merge backend.
+
+Replaces ``/root/reference/sd_mecha/streaming.py`` for the hot path:
+
+* ``InSafetensorsDict`` (reference :85-178: lock + buffered ``readinto`` + ``clone``) becomes a read-only
+  **mmap** of the file: ``raw(key)`` returns a zero-copy byte view that the scheduler copies straight into a
+  pinned staging buffer -- no per-file lock, no intermediate copies.  ``__getitem__`` keeps the reference
+  behaviour (a torch tensor copy) for user-defined methods.
+* ``OutSafetensorsDict`` (reference :204-350) keeps the file format decisions that are observable:
+  8-byte little-endian header length, JSON header with ``__metadata__.mecha_recipe``, header space reserved
+  up front from a worst-case header and padded with spaces at ``close()`` (reference :256-275, :346-350),
+  tensors appended in completion order.  Writes are positional (``os.pwrite``) so a sharded job can fill
+  one file from several processes (``reserve()`` hands out disjoint regions).
+
+Same error types as the reference: a missing key raises ``StateDictKeyError``; non-``.safetensors`` paths
+are rejected (reference :87-88).
+"""
+from __future__ import annotations
+
+import json
+import mmap
+import os
+import pathlib
+import struct
+import threading
+from collections import OrderedDict
+from typing import Dict, Iterable, Iterator, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .merge_methods import StateDictKeyError
+
+# safetensors dtype tag -> (torch dtype, bytes per element); reference streaming.py:395-425
+DTYPE_MAPPING = {
+    "F64": (torch.float64, 8), "I64": (torch.int64, 8), "F32": (torch.float32, 4), "I32": (torch.int32, 4),
+    "F16": (torch.float16, 2), "BF16": (torch.bfloat16, 2), "I16": (torch.int16, 2), "I8": (torch.int8, 1),
+    "U8": (torch.uint8, 1), "BOOL": (torch.bool, 1),
+}
+DTYPE_REVERSE_MAPPING = {v[0]: (k, v[1]) for k, v in DTYPE_MAPPING.items()}
+
+
+class TensorMetadata:
+    __slots__ = ("shape", "dtype", "start", "end")
+
+    def __init__(self, shape, dtype, start=0, end=0):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = dtype
+        self.start, self.end = int(start), int(end)
+
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    def nbytes(self) -> int:
+        return self.numel() * DTYPE_REVERSE_MAPPING[self.dtype][1]
+
+    def __repr__(self):
+        return f"TensorMetadata(shape={self.shape}, dtype={self.dtype})"
+
+
+def read_header(path: pathlib.Path) -> Tuple[int, Dict[str, dict]]:
+    """8-byte LE length + JSON (reference :141-149).  Returns (header_size, header sorted by data offset)."""
+    with open(path, "rb") as f:
+        size_bytes = f.read(8)
+        if len(size_bytes) != 8:
+            raise ValueError(f"{path}: not a safetensors file (too short)")
+        (header_size,) = struct.unpack("<Q", size_bytes)
+        header = json.loads(f.read(header_size).decode("utf-8").strip())
+    ordered = OrderedDict(sorted(header.items(), key=lambda kv: kv[1].get("data_offsets", [0])[0] if isinstance(kv[1], dict) else 0))
+    return header_size, ordered
+
+
+class InSafetensorsDict(Mapping):
+    """Read side (protocol of reference :59-82: keys / metadata / __getitem__ / close)."""
+
+    def __init__(self, file_path, buffer_size: int = 0):
+        file_path = pathlib.Path(file_path)
+        if file_path.suffix != ".safetensors":
+            raise ValueError(f"Model type not supported: {file_path} (only safetensors are supported)")
+        self.file_path = file_path
+        self.header_size, self.header = read_header(file_path)
+        self.data_start = 8 + self.header_size
+        self._file = open(file_path, "rb")
+        size = os.fstat(self._file.fileno()).st_size
+        self._mmap = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ) if size > 0 else None
+        self._view = memoryview(self._mmap) if self._mmap is not None else memoryview(b"")
+        self._meta = {
+            k: TensorMetadata(v["shape"], DTYPE_MAPPING[v["dtype"]][0], *v["data_offsets"])
+            for k, v in self.header.items() if k != "__metadata__"
+        }
+
+    # ---- mapping protocol
+    def __contains__(self, key):
+        return key in self._meta
+
+    def __len__(self):
+        return len(self._meta)
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self._meta)
+
+    def keys(self) -> Iterable[str]:
+        return self._meta.keys()
+
+    def metadata(self) -> Iterable[Tuple[str, TensorMetadata]]:
+        return self._meta.items()
+
+    def file_metadata(self) -> dict:
+        return dict(self.header.get("__metadata__", {}) or {})
+
+    def meta(self, key: str) -> TensorMetadata:
+        try:
+            return self._meta[key]
+        except KeyError as e:
+            raise StateDictKeyError(key) from e
+
+    def raw(self, key: str, start_elem: int = 0, n_elems: Optional[int] = None) -> memoryview:
+        """Zero-copy bytes of (a row range of) a tensor inside the mmap."""
+        m = self.meta(key)
+        esz = DTYPE_REVERSE_MAPPING[m.dtype][1]
+        lo = self.data_start + m.start + start_elem * esz
+        hi = self.data_start + m.end if n_elems is None else lo + n_elems * esz
+        return self._view[lo:hi]
+
+    def __getitem__(self, key: str) -> torch.Tensor:
+        m = self.meta(key)
+        if m.end == m.start:
+            return torch.tensor([], dtype=m.dtype).reshape(m.shape)          # reference :169-170
+        buf = bytearray(self.raw(key))                                       # one copy, like the reference's clone()
+        return torch.frombuffer(buf, dtype=m.dtype).view(m.shape)
+
+    def close(self):
+        if getattr(self, "_view", None) is not None:
+            self._view.release()
+            self._view = None
+        if getattr(self, "_mmap", None) is not None:
+            self._mmap.close()
+            self._mmap = None
+        if getattr(self, "_file", None) is not None:
+            self._file.close()
+            self._file = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _worst_case_header_size(header: Mapping[str, TensorMetadata], metadata: dict) -> int:
+    """reference :256-275: size of the header if tensors were laid out largest first."""
+    dummy = OrderedDict()
+    dummy["__metadata__"] = metadata
+    off = 0
+    for k, m in sorted(header.items(), key=lambda kv: kv[1].nbytes(), reverse=True):
+        dummy[k] = {"dtype": DTYPE_REVERSE_MAPPING[m.dtype][0], "shape": list(m.shape), "data_offsets": [off, off + m.nbytes()]}
+        off += m.nbytes()
+    return len(json.dumps(dummy, separators=(",", ":")).encode("utf-8"))
+
+
+class OutSafetensorsDict:
+    """Write side.  ``put(key, meta, data_bytes)`` appends; ``close()`` writes the header.
+
+    One instance per writing process.  For a job sharded over ranks every rank opens the same file with
+    ``create=(rank == 0)`` and a disjoint ``[region_start, region_end)`` of the data section; rank 0 merges
+    the sub-headers (``close(extra_entries=...)``)."""
+
+    def __init__(self, file_path, header: Mapping[str, TensorMetadata], mecha_recipe: Optional[str], *,
+                 create: bool = True, region_start: int = 0):
+        self.file_path = pathlib.Path(file_path)
+        self.metadata = {"mecha_recipe": mecha_recipe} if mecha_recipe is not None else {}
+        self.max_header_size = _worst_case_header_size(header, self.metadata)
+        self.data_start = 8 + self.max_header_size
+        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
+        self._fd = os.open(self.file_path, flags, 0o644)
+        self._lock = threading.Lock()
+        self._cursor = region_start                       # next free byte of this writer's region (data-section relative)
+        self.entries: Dict[str, dict] = {}
+
+    def put(self, key: str, meta: TensorMetadata, data) -> None:
+        """Append one tensor (any bytes-like of exactly meta.nbytes())."""
+        view = memoryview(data).cast("B") if not isinstance(data, memoryview) else data.cast("B")
+        if len(view) != meta.nbytes():
+            raise ValueError(f"{key}: got {len(view)} bytes, expected {meta.nbytes()}")
+        with self._lock:
+            off = self._cursor
+            self._cursor += len(view)
+        written = 0
+        while written < len(view):
+            written += os.pwrite(self._fd, view[written:], self.data_start + off + written)
+        self.entries[key] = {"dtype": DTYPE_REVERSE_MAPPING[meta.dtype][0], "shape": list(meta.shape), "data_offsets": [off, off + len(view)]}
+
+    def __setitem__(self, key: str, tensor: torch.Tensor) -> None:
+        """WriteOnlyMapping protocol of the reference (typing_.py:12-20): tensor -> bytes -> file."""
+        t = tensor.detach().cpu().contiguous()
+        meta = TensorMetadata(t.shape, t.dtype)
+        data = t.view(torch.uint8).numpy().tobytes() if t.numel() else b""
+        self.put(key, meta, data)
+
+    @property
+    def bytes_written(self) -> int:
+        return self._cursor
+
+    def close(self, extra_entries: Optional[Mapping[str, dict]] = None, write_header: bool = True) -> None:
+        if self._fd is None:
+            return
+        if write_header:
+            header = OrderedDict()
+            header["__metadata__"] = self.metadata
+            entries = dict(self.entries)
+            if extra_entries:
+                entries.update(extra_entries)
+            for k, v in sorted(entries.items(), key=lambda kv: kv[1]["data_offsets"][0]):
+                header[k] = v
+            blob = json.dumps(header, separators=(",", ":")).encode("utf-8")
+            if len(blob) > self.max_header_size:
+                raise RuntimeError("safetensors header outgrew its reserved space")   # cannot happen: worst case reserved
+            os.pwrite(self._fd, struct.pack("<Q", self.max_header_size), 0)
+            os.pwrite(self._fd, blob + b" " * (self.max_header_size - len(blob)), 8)
+        os.close(self._fd)
+        self._fd = None
+
+    def __del__(self):
+        try:
+            if self._fd is not None:
+                os.close(self._fd)
+        except Exception:
+            pass
+
+
+def compact_holes(file_path, chunk: int = 1 << 26) -> None:
+    """Rewrite a safetensors file whose data section has unused gaps (keys skipped at run time by a sharded
+    job) so that tensors are contiguous, as the format requires.  Rare path: O(file size)."""
+    file_path = pathlib.Path(file_path)
+    header_size, header = read_header(file_path)
+    entries = [(k, v) for k, v in header.items() if k != "__metadata__"]
+    entries.sort(key=lambda kv: kv[1]["data_offsets"][0])
+    data_start = 8 + header_size
+    fd = os.open(file_path, os.O_RDWR)
+    try:
+        cursor = 0
+        for k, v in entries:
+            lo, hi = v["data_offsets"]
+            if lo != cursor:
+                moved = 0
+                while moved < hi - lo:
+                    n = min(chunk, hi - lo - moved)
+                    buf = os.pread(fd, n, data_start + lo + moved)
+                    os.pwrite(fd, buf, data_start + cursor + moved)
+                    moved += n
+                v["data_offsets"] = [cursor, cursor + hi - lo]
+            cursor += hi - lo
+        os.ftruncate(fd, data_start + cursor)
+        out = OrderedDict()
+        out["__metadata__"] = header.get("__metadata__", {})
+        for k, v in entries:
+            out[k] = v
+        blob = json.dumps(out, separators=(",", ":")).encode("utf-8")
+        assert len(blob) <= header_size
+        os.pwrite(fd, blob + b" " * (header_size - len(blob)), 8)
+    finally:
+        os.close(fd)
