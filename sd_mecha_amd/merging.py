@@ -35,7 +35,7 @@ from . import merge_methods as mm
 from .arena import ArenaLayout, plan_arena, shard_keys_lpt
 from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError
 from .recipe_nodes import LiteralRecipeNode, MergeRecipeNode, ModelRecipeNode, RecipeNode, serialize, value_to_node
-from .streaming import DTYPE_REVERSE_MAPPING, InSafetensorsDict, OutSafetensorsDict, TensorMetadata, compact_holes
+from .streaming import DTYPE_REVERSE_MAPPING, InSafetensorsDict, OutSafetensorsDict, TensorMetadata, compact_holes, tensor_bytes
 
 _DT_CODE = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 log = logging.getLogger("sd_mecha_amd")
@@ -99,12 +99,24 @@ def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
             models = []
             for d in t.args:
                 if not (isinstance(d, MergeRecipeNode) and d.merge_method.identifier == "subtract" and len(d.args) == 2
-                        and isinstance(d.args[0], ModelRecipeNode) and d.args[1] is base):
+                        and isinstance(d.args[0], ModelRecipeNode) and _same_model(d.args[1], base)):
                     return None
                 models.append(d.args[0])
             if k is not None and models and len(models) < _lib.MAX_MODELS and not math.isclose(alpha, 0.0):
                 return FusedPlan("ties", [base] + models, {"k": k, "alpha": alpha, "vote_sgn": vote}, fallback)
+    if ident == "add_difference_ties":
+        k = _scalar(recipe.kwargs.get("k"), 0.2) if "k" in recipe.kwargs else 0.2
+        alpha = _scalar(recipe.kwargs.get("alpha"), 1.0) if "alpha" in recipe.kwargs else 1.0
+        vote = recipe.kwargs.get("vote_sgn")
+        vote = bool(vote.value) if isinstance(vote, LiteralRecipeNode) else False
+        if (len(recipe.args) >= 2 and all(isinstance(a, ModelRecipeNode) for a in recipe.args) and k is not None and alpha is not None
+                and not math.isclose(alpha, 0.0) and len(recipe.args) <= _lib.MAX_MODELS):
+            return FusedPlan("ties", list(recipe.args), {"k": k, "alpha": alpha, "vote_sgn": vote}, fallback)
     return None
+
+
+def _same_model(a: RecipeNode, b: RecipeNode) -> bool:
+    return a is b or (isinstance(a, ModelRecipeNode) and isinstance(b, ModelRecipeNode) and a.path == b.path)
 
 
 def collect_models(recipe: RecipeNode) -> List[ModelRecipeNode]:
@@ -452,7 +464,7 @@ def _write_fallback(plan, readers, key, meta, sink, to_file, output_device, outp
         return False                                                          # the fallback's own omit_non_finite
     t = t.to(output_dtype)
     if to_file:
-        sink.put(key, meta, t.contiguous().view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+        sink.put(key, meta, tensor_bytes(t))
     else:
         sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t
     return True

@@ -61,6 +61,12 @@ class TensorMetadata:
         return f"TensorMetadata(shape={self.shape}, dtype={self.dtype})"
 
 
+def tensor_bytes(t: torch.Tensor) -> bytes:
+    """Raw little-endian bytes of a CPU tensor (0-d and empty tensors included)."""
+    t = t.detach().cpu().contiguous()
+    return t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b""
+
+
 def read_header(path: pathlib.Path) -> Tuple[int, Dict[str, dict]]:
     """8-byte LE length + JSON (reference :141-149).  Returns (header_size, header sorted by data offset)."""
     with open(path, "rb") as f:
@@ -195,10 +201,7 @@ class OutSafetensorsDict:
 
     def __setitem__(self, key: str, tensor: torch.Tensor) -> None:
         """WriteOnlyMapping protocol of the reference (typing_.py:12-20): tensor -> bytes -> file."""
-        t = tensor.detach().cpu().contiguous()
-        meta = TensorMetadata(t.shape, t.dtype)
-        data = t.view(torch.uint8).numpy().tobytes() if t.numel() else b""
-        self.put(key, meta, data)
+        self.put(key, TensorMetadata(tensor.shape, tensor.dtype), tensor_bytes(tensor))
 
     @property
     def bytes_written(self) -> int:
