@@ -162,6 +162,18 @@ int mecha_ties_sum_with_dropout(const void *const *deltas, int n_models, const u
 int mecha_dare_draw_masks_host(uint64_t seed, float probability, int n_models, int64_t numel,
                                uint32_t *bits_out);
 
+/* LoRA / LyCORIS reconstruction (extensions/builtin/lycoris.py:226-263, LoraAlgorithm.compose / compose_alpha) fused
+ * with add_difference (linear.py:64-76) for every network of one key:
+ *   out = base; for each network i in order: out = fma((up_i @ down_i) * scales[i], weights[i], out)
+ * up_i is [rows, ranks[i]] row-major (up.view(out, -1)), down_i is [ranks[i], cols] (down.view(r, -1)); both of dtype
+ * `lora_dtype` (MECHA_F16 or MECHA_BF16: the MFMA path multiplies 16-bit operands exactly, accumulates in fp32).
+ * scales[i] = alpha_i / r_i (compose_alpha, lycoris.py:258-263) or 1 (compose); weights[i] = the add_difference alpha
+ * (a network with weight == 0 is skipped, linear.py:72-73).  base == NULL computes the (sum of) deltas only.
+ * ups / downs / ranks / scales / weights are HOST arrays of n_networks entries (<= MECHA_MAX_MODELS). */
+int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t cols, int base_dtype, int out_dtype,
+                          const void *const *ups, const void *const *downs, const int32_t *ranks, const float *scales,
+                          const float *weights, int n_networks, int lora_dtype, uint32_t *flags, void *stream);
+
 /* ------------------------------------------------------------------ batched
  * The key scheduler's form (replaces the per-key futures loop of merging.py:223-229
  * for recognised recipe graphs): every model's shard lives in one arena with

@@ -355,3 +355,70 @@ def ties_sum_with_dropout(*deltas, probability=0.9, della_eps: float = 0.0, resc
                                              None, ws.data_ptr(), ws.numel(), fl.ptr, _stream()), "mecha_ties_sum_with_dropout")
     fl.finish(None)
     return out
+
+
+# ------------------------------------------------------------------ lycoris.py
+def _lora_network(up: torch.Tensor, down: torch.Tensor, alpha):
+    """(up2d, down2d, rank, scale) of one network: up.view(out, -1), down.view(r, -1), alpha / r or 1 (lycoris.py:228-263)."""
+    if up.dim() < 2 or down.dim() < 2:
+        raise ValueError("lora_up / lora_down must be at least 2-D")
+    rank = down.shape[0]
+    up2, down2 = _c(up).reshape(up.shape[0], -1), _c(down).reshape(rank, -1)
+    if up2.shape[1] != rank:
+        raise ValueError(f"lora_up {tuple(up.shape)} does not match lora_down {tuple(down.shape)} (rank {rank}); "
+                         "lora_mid / Tucker networks are outside the MI355X path")
+    if alpha is None:
+        scale = 1.0
+    else:
+        a = torch.as_tensor(alpha).detach().to("cpu", torch.float32)
+        scale = float((a / rank).item())                    # 0-d fp32 tensor divided by a python int (lycoris.py:263)
+    return up2, down2, rank, scale
+
+
+def lora_merge(base: Optional[torch.Tensor], networks, target_shape=None, *, key=None, out_dtype=None, flags=None,
+               check_finite=True) -> torch.Tensor:
+    """The LoRA recipe of SURVEY.md §3.4 for one key, every network in one pass over the base tensor:
+    ``for (up, down, alpha, weight) in networks: base = add_difference(base, compose(up, down, alpha), weight)``
+    (lycoris.py:226-263 + linear.py:64-76).  ``base=None`` returns the (weighted sum of the) deltas in ``target_shape``."""
+    nets = [_lora_network(up, down, alpha) + (float(w),) for up, down, alpha, w in networks]
+    if not nets:
+        raise ValueError("lora_merge needs at least one network")
+    rows, cols = nets[0][0].shape[0], nets[0][1].shape[1]
+    lora_dtype = nets[0][0].dtype
+    for up2, down2, rank, _, _ in nets:
+        if up2.shape[0] != rows or down2.shape[1] != cols or up2.dtype != lora_dtype or down2.dtype != lora_dtype:
+            raise ValueError("all networks of one key must produce the same [out, in] delta and share a dtype")
+        if not up2.is_cuda or not down2.is_cuda:
+            raise RuntimeError("LoRA factors must be on the ROCm device; the MI355X backend has no CPU path")
+    if lora_dtype not in (torch.float16, torch.bfloat16):
+        raise NotImplementedError(f"LoRA factors of dtype {lora_dtype}: the MFMA path takes float16 / bfloat16 factors")
+    if len(nets) > _lib.MAX_MODELS:
+        raise ValueError(f"at most {_lib.MAX_MODELS} networks per call")
+    if base is not None:
+        base = _c(base)
+        _check_inputs([base], "lora_merge")
+        if base.numel() != rows * cols:
+            raise ValueError(f"base has {base.numel()} elements, the networks produce {rows} x {cols}")
+        shape = base.shape
+    else:
+        shape = tuple(target_shape) if target_shape is not None else (rows, cols)
+    dev = nets[0][0].device
+    out = torch.empty(shape, dtype=out_dtype or torch.float32, device=dev)
+    if out.numel() != rows * cols:
+        raise ValueError(f"target shape {tuple(shape)} does not hold {rows} x {cols} elements")
+    n = len(nets)
+    ranks = (ctypes.c_int32 * n)(*[t[2] for t in nets])
+    scales = (ctypes.c_float * n)(*[t[3] for t in nets])
+    weights = (ctypes.c_float * n)(*[t[4] for t in nets])
+    fl = _Flags(dev, flags, check_finite)
+    _lib.check(_lib.lib().mecha_lora_accumulate(
+        base.data_ptr() if base is not None else None, out.data_ptr(), rows, cols, _DT[base.dtype] if base is not None else F32,
+        _DT[out.dtype], _lib.ptr_array([t[0].data_ptr() for t in nets]), _lib.ptr_array([t[1].data_ptr() for t in nets]),
+        ranks, scales, weights, n, _DT[lora_dtype], fl.ptr, _stream()), "mecha_lora_accumulate")
+    fl.finish(key)
+    return out
+
+
+def lora_delta(up: torch.Tensor, down: torch.Tensor, alpha=None, target_shape=None, *, out_dtype=None) -> torch.Tensor:
+    """LoraAlgorithm.compose / compose_alpha (lycoris.py:226-263): (up @ down) * (alpha / r or 1), reshaped."""
+    return lora_merge(None, [(up, down, alpha, 1.0)], target_shape, out_dtype=out_dtype)

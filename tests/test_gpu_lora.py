@@ -1,0 +1,88 @@
+"""GPU parity of the MFMA LoRA reconstruction (sd_mecha_amd/csrc/lora.hip) against the reference's own
+LoraAlgorithm.compose / compose_alpha outputs (tests/golden/lora.npz) and against the oracle at larger sizes.
+Tolerance: the reference's fp32 sgemm order is BLAS-defined, so deltas are compared at fp32 level (rtol 1e-5 on an
+r-term dot product) and merged keys at <= 1 ulp of the output dtype."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ulp_distance_half
+
+pytestmark = pytest.mark.gpu
+
+TDT = {"bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def dev16(bits, dtype):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16).copy()).view(TDT[dtype]).cuda()
+
+
+def bits16(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def test_lora_golden():
+    import sd_mecha_amd as amd
+    g = load_golden("lora")
+    for c in range(int(g["n_cases"])):
+        pre = f"l{c}"
+        up, down = dev16(g[pre + "_up"], "float16"), dev16(g[pre + "_down"], "float16")
+        ts = tuple(int(x) for x in g[pre + "_target_shape"])
+        want = np.array(g[pre + "_delta_alpha4"], dtype=np.uint32).view(np.float32).reshape(ts)
+        got = amd.lora_delta(up, down, torch.tensor(4.0), ts).cpu().numpy()
+        assert got.shape == ts and np.allclose(got, want, rtol=1e-5, atol=1e-9)
+        want = np.array(g[pre + "_delta_noalpha"], dtype=np.uint32).view(np.float32).reshape(ts)
+        got = amd.lora_delta(up, down, None, ts).cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-9)
+        base = dev16(g[pre + "_base"], "bfloat16").reshape(ts)
+        merged = amd.lora_merge(base, [(up, down, 4.0, 0.75)], out_dtype=torch.bfloat16)
+        d = ulp_distance_half(bits16(merged).reshape(-1), g[pre + "_merged_0.75_bf16"].reshape(-1))
+        assert d.max() <= 1 and (d > 0).mean() < 0.002
+
+
+@pytest.mark.parametrize("ldt", ["float16", "bfloat16"])
+def test_lora_many_networks_vs_oracle(oracle, ldt):
+    """16 networks of mixed rank on one key, ragged sizes (not multiples of the 64x64 tile, rank not a multiple of 8)."""
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(21)
+    for rows, cols, ranks in [(640, 320 * 9, [32] * 16), (77, 131, [4, 8, 5, 16, 1]), (1280, 1280, [128, 64])]:
+        base_b = oracle.from_f32(rng.normal(0, 0.02, size=(rows, cols)).astype(np.float32), "bfloat16")
+        acc = oracle.to_f32(base_b, "bfloat16")
+        mag = np.abs(acc)
+        nets = []
+        for i, r in enumerate(ranks):
+            up_b = oracle.from_f32(rng.normal(0, 0.05, size=(rows, r)).astype(np.float32), ldt)
+            down_b = oracle.from_f32(rng.normal(0, 0.05, size=(r, cols)).astype(np.float32), ldt)
+            alpha, w = float(r) / 2, 1.0 if i % 2 == 0 else 0.6
+            delta = oracle.lora_delta(oracle.to_f32(up_b, ldt), oracle.to_f32(down_b, ldt), alpha)
+            acc = oracle.add_difference(acc, delta, w)
+            mag = mag + np.abs(delta)
+            nets.append((dev16(up_b, ldt), dev16(down_b, ldt), alpha, w))
+        got = amd.lora_merge(dev16(base_b, "bfloat16").reshape(rows, cols), nets, out_dtype=torch.bfloat16)
+        d = ulp_distance_half(bits16(got), oracle.from_f32(acc, "bfloat16"))
+        # <= 1 ulp of the output dtype; where base and deltas cancel (|result| << |terms|) the floor is the fp32
+        # rounding noise of the terms, not an ulp of the tiny result
+        noise = np.abs(got.float().cpu().numpy() - acc) <= 1e-6 * mag
+        assert ((d <= 1) | noise).all() and (d > 0).mean() < 0.005, (rows, cols, d.max(), (d > 0).mean())
+        # fp32 output, looser check of the accumulated value itself
+        got32 = amd.lora_merge(dev16(base_b, "bfloat16").reshape(rows, cols), nets).cpu().numpy()
+        assert np.allclose(got32, acc, rtol=2e-5, atol=1e-7)
+
+
+def test_lora_conv_shapes_and_validation():
+    import sd_mecha_amd as amd
+    up = torch.randn(32, 8, 1, 1, device="cuda").half()
+    down = torch.randn(8, 16, 3, 3, device="cuda").half()
+    base = torch.randn(32, 16, 3, 3, device="cuda").to(torch.bfloat16)
+    got = amd.lora_merge(base, [(up, down, 4.0, 1.0)], out_dtype=torch.float32)
+    want = base.float() + (up.float().view(32, 8) @ down.float().view(8, -1)).view(32, 16, 3, 3) * (4.0 / 8)
+    assert got.shape == base.shape and torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert torch.equal(amd.lora_merge(base, [(up, down, 4.0, 0.0)], out_dtype=torch.bfloat16), base)     # weight 0: base untouched
+    with pytest.raises(NotImplementedError):
+        amd.lora_merge(base, [(up.float(), down.float(), 4.0, 1.0)])
+    with pytest.raises(ValueError):
+        amd.lora_merge(base, [(up, down[:4], 4.0, 1.0)])
+    bad = up.clone()
+    bad[3, 2] = float("nan")
+    with pytest.raises(amd.NonFiniteStateDictKeyError):
+        amd.lora_merge(base, [(bad, down, 4.0, 1.0)], key="k")
