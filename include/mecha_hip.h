@@ -174,6 +174,19 @@ int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t col
                           const void *const *ups, const void *const *downs, const int32_t *ranks, const float *scales,
                           const float *weights, int n_networks, int lora_dtype, uint32_t *flags, void *stream);
 
+/* rotate (extensions/builtin/merge_methods/svd.py:10-86) at alignment = 1, alpha = 0 for one key already reshaped to
+ * n_rows x n_cols (svd.py:49-53): centre both matrices by their column means * centralization (svd.py:67-70),
+ * orthogonal_procrustes (svd.py:157-169; FullRankOrthogonalMatmul :194-206 for n_rows >= n_cols, LowRankOrthogonalMatmul
+ * :172-191 otherwise) with the A^T B contraction on f32 MFMA and the SVD as a one-sided Jacobi, apply the transform to
+ * the centred `a`, add b's mean (svd.py:84-85).  n_cols <= 8192.  The early-outs of svd.py:37-47 stay in the host shim
+ * (mecha_allclose_half implements the torch.allclose(a.half(), b.half()) test of :46).
+ * SYNCHRONISES `stream` once per Jacobi sweep (it reads one convergence counter).  `sweeps_out` (HOST int, may be NULL)
+ * receives the number of sweeps. */
+size_t mecha_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols);
+int mecha_rotate(const void *a, const void *b, void *out, int64_t n_rows, int64_t n_cols, int in_dtype, int out_dtype,
+                 float centralization, void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);
+int mecha_allclose_half(const void *a, const void *b, int64_t numel, int in_dtype, uint32_t *not_close, void *stream);
+
 /* ------------------------------------------------------------------ batched
  * The key scheduler's form (replaces the per-key futures loop of merging.py:223-229
  * for recognised recipe graphs): every model's shard lives in one arena with

@@ -40,6 +40,7 @@ add_difference_ties = merge_method(_mm.add_difference_ties)
 cast = merge_method(_mm.cast)
 omit_non_finite = merge_method(_mm.omit_non_finite)
 fallback = merge_method(_fallback, identifier="fallback")
+rotate = merge_method(_mm.rotate)
 lora_merge = merge_method(_mm.lora_merge)
 lora_delta = merge_method(_mm.lora_delta)
 

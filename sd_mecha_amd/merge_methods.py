@@ -419,6 +419,54 @@ def lora_merge(base: Optional[torch.Tensor], networks, target_shape=None, *, key
     return out
 
 
+# ------------------------------------------------------------------ svd.py
+def rotate_shape_2d(shape) -> tuple:
+    """svd.py:49-53: conv k x k keys flatten to (out * in, kh * kw), everything else to (out, rest)."""
+    shape = tuple(shape)
+    is_conv = len(shape) == 4 and shape[2] * shape[3] != 1
+    if is_conv:
+        return shape[0] * shape[1], shape[2] * shape[3]
+    rest = 1
+    for s in shape[1:]:
+        rest *= s
+    return shape[0], rest
+
+
+def rotate(a, b, alignment: float = 1.0, alpha=0.0, centralization: float = 1.0, stiefel_eps: float = 1e-8,
+           stiefel_max_iters: int = 100, *, key=None, cache=None, out_dtype=None, flags=None, check_finite=True,
+           return_sweeps: bool = False):
+    """rotate (svd.py:10-86).  On the MI355X path: alignment in {0, 1} with alpha == 0 (the benchmark
+    configuration); the early-outs of svd.py:37-47 are kept; fractional alignment, alpha != 0 and the ``cache`` of
+    factors raise NotImplementedError."""
+    al = _alpha(alpha)
+    if math.isclose(alignment, 0.0) and math.isclose(al, 0.0):
+        return cast(a, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
+    if math.isclose(alignment, 1.0) and math.isclose(al, 1.0):
+        return cast(b, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
+    a, b = _c(_resolve(a, key)), _c(_resolve(b, key))
+    _check_inputs([a, b], "rotate")
+    L = _lib.lib()
+    if a.dim() > 1 and a.numel() > 0:
+        word = torch.zeros(1, dtype=torch.int32, device=a.device)
+        _lib.check(L.mecha_allclose_half(a.data_ptr(), b.data_ptr(), a.numel(), _DT[a.dtype], word.data_ptr(), _stream()), "mecha_allclose_half")
+        same = int(word.item()) == 0
+    else:
+        same = True
+    if a.dim() <= 1 or same:
+        return weighted_sum(a, b, al, key=key, out_dtype=out_dtype, flags=flags, check_finite=check_finite)   # torch.lerp(a, b, alpha), svd.py:47
+    if not math.isclose(al, 0.0) or not math.isclose(alignment, 1.0) or cache is not None:
+        raise NotImplementedError("MI355X rotate covers alignment == 1 with alpha == 0 and no factor cache (SURVEY §8 a16)")
+    n, p = rotate_shape_2d(a.shape)
+    out = _out(a, out_dtype)
+    ws = _workspace(L.mecha_rotate_workspace_bytes(n, p), a.device)
+    sweeps = ctypes.c_int(0)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(L.mecha_rotate(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, _DT[a.dtype], _DT[out.dtype], float(centralization),
+                              ws.data_ptr(), ws.numel(), ctypes.byref(sweeps), fl.ptr, _stream()), "mecha_rotate")
+    fl.finish(key)
+    return (out, sweeps.value) if return_sweeps else out
+
+
 def lora_delta(up: torch.Tensor, down: torch.Tensor, alpha=None, target_shape=None, *, out_dtype=None) -> torch.Tensor:
     """LoraAlgorithm.compose / compose_alpha (lycoris.py:226-263): (up @ down) * (alpha / r or 1), reshaped."""
     return lora_merge(None, [(up, down, alpha, 1.0)], target_shape, out_dtype=out_dtype)
