@@ -194,7 +194,7 @@ def main():
         per_launch_bytes = {
             "streaming_ew": elems * 2 * (job.n_models + 1),
             "ties_hist1": elems * 2 * job.n_models, "ties_hist2": elems * 2 * job.n_models, "ties_hist3": elems * 2 * job.n_models,
-            "ties_merge": elems * 2 * (job.n_models + 1),
+            "ties_count": elems * 2 * job.n_models, "ties_merge": elems * 2 * (job.n_models + 1),
         }
         breakdown = {k: {"ms_total": round(ms, 3), "launches": n, "ms_avg": round(ms / n, 4)} for k, (ms, n) in kernels.items()}
         dom = max((k for k in kernels if k in per_launch_bytes), key=lambda k: kernels[k][0])
@@ -213,6 +213,13 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch_bytes[dom], "avg_launch_ms": round(dom_ms, 4)},
             "kernels": breakdown,
         }
+        if job.recipe == "ties":
+            failed, amb = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+            _lib.check(job.lib.mecha_ties_select_stats(job.ws.data_ptr(), job.n_models - 1, len(job.layout.keys), job.layout.total_elems,
+                                                       ctypes.byref(failed), ctypes.byref(amb),
+                                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ties stats")
+            line["ties_select"] = {"pairs": len(job.layout.keys) * (job.n_models - 1), "pairs_fell_back_to_radix": failed.value,
+                                   "elements_in_ambiguous_lists": amb.value}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(job, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -138,12 +138,23 @@ int mecha_ties_sum(const void *const *deltas, int n_models, void *out, int64_t n
 /* The TIES recipe graph of wrappers.py:70-94 in one fused pipeline:
  *   out = add_difference(base, ties_sum(m_0 - base, ..., m_{n-1} - base, k), alpha)
  * (subtract linear.py:101, ties_sum ties.py:98-125, add_difference linear.py:76).
- * Reads base and every model once per radix pass and once in the merge pass;
- * no fp32 delta is ever materialised. */
+ * Reads base and every model once in the selection pass (three more times for a (key, delta)
+ * pair whose bracket misses) and once in the merge pass; no fp32 delta is ever materialised.
+ * Environment variable MECHA_TIES_SELECT=radix|fail (tests): force the radix-select pipeline /
+ * force every bracket to miss. */
 int mecha_add_difference_ties(const void *base, const void *const *models, int n_models, void *out,
                               int64_t numel, int in_dtype, int out_dtype, double k, float alpha,
                               int vote_sgn, float *thresholds_out, void *workspace,
                               size_t workspace_bytes, uint32_t *flags, void *stream);
+
+/* Diagnostics of the last TIES call that used `workspace` (sized for the same n_models,
+ * n_segments (1 for the per-key entry points), total_elems (numel for per-key)): how many
+ * (key, delta) pairs fell back to the radix select, and how many elements went through the
+ * ambiguous lists.  Synchronises `stream`.  No counterpart in the reference (torch.kthvalue,
+ * ties.py:130, has no such state); used by bench.py and the tests. */
+int mecha_ties_select_stats(const void *workspace, int n_models, int n_segments, int64_t total_elems,
+                            unsigned long long *failed_pairs, unsigned long long *ambiguous_elems,
+                            void *stream);
 
 /* DARE: ties_sum_with_dropout (ties.py:10-50) with della_eps == 0, apply_median == False and
  * apply_stock == True (t = 1, ties.py:90).  `keep_bits`: device uint32[n_models][ceil(numel/32)],

@@ -42,7 +42,8 @@ static inline bool mecha_aligned16(const void *p) { return (reinterpret_cast<uin
 // stream; mecha_profile_read sums the elapsed times per kernel family.  bench.py uses this for `roofline`.
 enum MechaKernelId : int {
     MK_STREAMING = 0, MK_TIES_INDEX, MK_TIES_HIST1, MK_TIES_HIST2, MK_TIES_HIST3, MK_TIES_SCAN, MK_TIES_MERGE,
-    MK_RED_REDUCE, MK_RED_FINISH, MK_RED_APPLY, MK_RED_FIXUP, MK_LORA, MK_ROT_GEMM, MK_ROT_JACOBI, MK_COUNT
+    MK_RED_REDUCE, MK_RED_FINISH, MK_RED_APPLY, MK_RED_FIXUP, MK_LORA, MK_ROT_GEMM, MK_ROT_JACOBI,
+    MK_TIES_SAMPLE, MK_TIES_COUNT, MK_TIES_RESOLVE, MK_TIES_FIXUP, MK_COUNT
 };
 extern bool g_mecha_profiling;
 void mecha_prof_begin(hipStream_t s, int id);
@@ -81,14 +82,21 @@ __device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
 __device__ __forceinline__ bool nonfinite_f32(float f) { return (__float_as_uint(f) & 0x7f800000u) == 0x7f800000u; }
 
 // Load 8 consecutive elements starting at element index i (i % 8 == 0, base 16-B aligned) as fp32.
-template <int DT>
+// NT = non-temporal: for data a kernel touches exactly once (measured on the streaming merge shape, tools/stream_bench.hip:
+// contiguous chunk per block + 2 vectors in flight + nt = 5.1-5.4 TB/s against 4.0-4.7 TB/s for a grid-stride loop).
+template <int DT, bool NT = false>
 __device__ __forceinline__ void load8(const void *base, int64_t i, float (&v)[8]) {
     if constexpr (DT == MECHA_F32) {
         const f32x4 *p = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(base) + i);
-        f32x4 a = p[0], b = p[1];
+        f32x4 a, b;
+        if constexpr (NT) { a = __builtin_nontemporal_load(p); b = __builtin_nontemporal_load(p + 1); }
+        else { a = p[0]; b = p[1]; }
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
-        u32x4 r = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(base) + i);
+        const u32x4 *q = reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(base) + i);
+        u32x4 r;
+        if constexpr (NT) r = __builtin_nontemporal_load(q);
+        else r = *q;
         uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -102,6 +110,29 @@ __device__ __forceinline__ void load8(const void *base, int64_t i, float (&v)[8]
         }
     }
 }
+// The same for 16-bit storage in two steps, so that a kernel can keep many loads in flight as raw words
+// (4 VGPRs per vector instead of 8) and convert when it consumes them.
+template <bool NT>
+__device__ __forceinline__ u32x4 load_raw16(const void *base, int64_t i) {
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(base) + i);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+template <int DT>
+__device__ __forceinline__ void unpack16(u32x4 r, float (&v)[8]) {
+    static_assert(DT != MECHA_F32, "16-bit storage only");
+    uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if constexpr (DT == MECHA_BF16) {
+            v[2 * j] = __uint_as_float(w[j] << 16);
+            v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        } else {
+            v[2 * j] = f16_bits_to_f32(w[j] & 0xffffu);
+            v[2 * j + 1] = f16_bits_to_f32(w[j] >> 16);
+        }
+    }
+}
 // Scalar element load (tails and unaligned tensors).
 template <int DT>
 __device__ __forceinline__ float load1(const void *base, int64_t i) {
@@ -109,12 +140,13 @@ __device__ __forceinline__ float load1(const void *base, int64_t i) {
     else if constexpr (DT == MECHA_BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(base)[i]);
     else return f16_bits_to_f32(reinterpret_cast<const uint16_t *>(base)[i]);
 }
-template <int DT>
+template <int DT, bool NT = false>
 __device__ __forceinline__ void store8(void *base, int64_t i, const float (&v)[8]) {
     if constexpr (DT == MECHA_F32) {
         f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(base) + i);
         f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-        p[0] = a; p[1] = b;
+        if constexpr (NT) { __builtin_nontemporal_store(a, p); __builtin_nontemporal_store(b, p + 1); }
+        else { p[0] = a; p[1] = b; }
     } else {
         uint32_t w[4];
 #pragma unroll
@@ -123,7 +155,9 @@ __device__ __forceinline__ void store8(void *base, int64_t i, const float (&v)[8
             else w[j] = f32_to_f16_bits(v[2 * j]) | (f32_to_f16_bits(v[2 * j + 1]) << 16);
         }
         u32x4 r = {w[0], w[1], w[2], w[3]};
-        *reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(base) + i) = r;
+        u32x4 *q = reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(base) + i);
+        if constexpr (NT) __builtin_nontemporal_store(r, q);
+        else *q = r;
     }
 }
 template <int DT>

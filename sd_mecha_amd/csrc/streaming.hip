@@ -32,13 +32,36 @@ struct EwParams {
 template <int OP, int IN_DT, bool VEC>
 __device__ __forceinline__ void compute8(const EwParams &p, int64_t i, int valid, float (&r)[8], bool &bad_in) {
     auto ld = [&](const void *base, float (&v)[8]) {
-        if constexpr (VEC) load8<IN_DT>(base, i, v);
+        if constexpr (VEC) load8<IN_DT, true>(base, i, v);          // every input element is read exactly once
         else {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = (j < valid) ? load1<IN_DT>(base, i + j) : 0.0f;
         }
     };
-    if constexpr (OP == OP_NAVG) {
+    if constexpr (OP == OP_NAVG && VEC && IN_DT != MECHA_F32) {
+        // 16-bit storage: up to 8 loads in flight as raw words (4 VGPRs each), converted as they are consumed
+        for (int g = 0; g < p.n_in; g += 8) {
+            u32x4 raw[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++)
+                if (g + m < p.n_in) raw[m] = load_raw16<true>(p.in[g + m], i);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                if (g + m < p.n_in) {
+                    const int idx = g + m;
+                    const float w = p.w[idx], wm1 = p.wm1[idx];
+                    const bool small = idx >= 2;
+                    float v[8];
+                    unpack16<IN_DT>(raw[m], v);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        bad_in |= nonfinite_f32(v[j]);
+                        r[j] = (idx == 0) ? v[j] : lerp_torch(r[j], v[j], w, wm1, small);
+                    }
+                }
+            }
+        }
+    } else if constexpr (OP == OP_NAVG) {
         for (int g = 0; g < p.n_in; g += 8) {
             float v[8][8];
 #pragma unroll
@@ -83,9 +106,12 @@ __device__ __forceinline__ void compute8(const EwParams &p, int64_t i, int valid
 template <int OP, int IN_DT, int OUT_DT, bool VEC, bool HAS_OUT>
 __global__ __launch_bounds__(MECHA_BLOCK) void ew_kernel(EwParams p, void *out, int64_t total,
                                                           const mecha_segment *segs, int n_segs, uint32_t *flags) {
+    // each block sweeps ONE contiguous chunk of the range (measured +17 % over a grid-stride loop, tools/stream_bench.hip)
     const int64_t n_vec = (total + 7) >> 3;
-    const int64_t stride = (int64_t)gridDim.x * MECHA_BLOCK;
-    for (int64_t v = (int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x; v < n_vec; v += stride) {
+    const int64_t per_block = ((n_vec + gridDim.x - 1) / gridDim.x + MECHA_BLOCK - 1) / MECHA_BLOCK * MECHA_BLOCK;
+    const int64_t v_begin = (int64_t)blockIdx.x * per_block;
+    const int64_t v_end = (v_begin + per_block < n_vec) ? v_begin + per_block : n_vec;
+    for (int64_t v = v_begin + threadIdx.x; v < v_end; v += MECHA_BLOCK) {
         const int64_t i = v << 3;
         const int valid = (total - i >= 8) ? 8 : (int)(total - i);
         float r[8];
@@ -96,7 +122,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ew_kernel(EwParams p, void *out, 
 #pragma unroll
         for (int j = 0; j < 8; j++) bad_out |= (j < valid) && nonfinite_f32(r[j]);
         if constexpr (HAS_OUT) {
-            if (VEC && valid == 8) store8<OUT_DT>(out, i, r);
+            if (VEC && valid == 8) store8<OUT_DT, true>(out, i, r);
             else {
 #pragma unroll
                 for (int j = 0; j < 8; j++)
@@ -145,8 +171,10 @@ int launch_ew(EwParams &p, void *out, int64_t total, int in_dt, int out_dt, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     MECHA_DISPATCH_DTYPES(in_dt, out_dt, {
         if (out == nullptr) {
-            if (vec) MECHA_LAUNCH(MK_STREAMING, (ew_kernel<OP, IN_DT, OUT_DT, true, false>), grid, block, 0, s, p, out, total, segs, n_segs, flags);
-            else MECHA_LAUNCH(MK_STREAMING, (ew_kernel<OP, IN_DT, OUT_DT, false, false>), grid, block, 0, s, p, out, total, segs, n_segs, flags);
+            if constexpr (OP == OP_CAST) {                      // finite check only (omit_non_finite)
+                if (vec) MECHA_LAUNCH(MK_STREAMING, (ew_kernel<OP, IN_DT, OUT_DT, true, false>), grid, block, 0, s, p, out, total, segs, n_segs, flags);
+                else MECHA_LAUNCH(MK_STREAMING, (ew_kernel<OP, IN_DT, OUT_DT, false, false>), grid, block, 0, s, p, out, total, segs, n_segs, flags);
+            }
         } else {
             if (vec) MECHA_LAUNCH(MK_STREAMING, (ew_kernel<OP, IN_DT, OUT_DT, true, true>), grid, block, 0, s, p, out, total, segs, n_segs, flags);
             else MECHA_LAUNCH(MK_STREAMING, (ew_kernel<OP, IN_DT, OUT_DT, false, true>), grid, block, 0, s, p, out, total, segs, n_segs, flags);

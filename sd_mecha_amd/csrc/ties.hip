@@ -3,23 +3,34 @@
 // Reference: extensions/builtin/merge_methods/ties.py:98-132 (ties_sum, ties_sum_deltas, filter_top_k),
 // ties.py:10-50 (ties_sum_with_dropout), linear.py:101 (subtract), linear.py:76 (add_difference).
 //
-// Pipeline (one key, or every key of an arena in the batched form -- same kernels):
-//   hist<1> -> scan<1> -> hist<2> -> scan<2> -> hist<3> -> scan<3> -> merge
-// The threshold of delta m is the kth-smallest |delta_m| (kth = max(int((1-k)*numel), 1)), found exactly
-// by a most-significant-digit radix select on the fp32 bit pattern of |delta| (31 value bits split
-// 11 / 11 / 9).  hist<p> counts, per (key, delta), the elements whose already-selected prefix matches, by
-// their next digit: LDS atomics into a per-block histogram, flushed to the global per-(key, delta)
-// histogram with one atomic per non-empty bin.  scan<p> (one block per (key, delta)) walks the 2048 bins,
-// picks the digit that holds rank kth, and zeroes the histogram for the next pass.
-// merge recomputes the deltas, applies |delta| >= threshold (ties kept), elects the sign, averages the
-// agreeing deltas, and fuses add_difference + output cast + finite checks.
+// The threshold of delta m is the kth-smallest |delta_m| (kth = max(int((1-k)*numel), 1), ties kept), exact.
+// Two selection pipelines (one key, or every key of an arena in the batched form -- same kernels):
 //
-// No fp32 delta is ever written to memory.  Roofline: HBM.  Algorithmic bytes per element for the fused
-// graph = in_size * (n_models + 1) + out_size (10 B for base + 3 models in bf16); the three
-// hist passes re-read the inputs (implementation traffic, reported separately in DESIGN.md).
+//  A. bracket select (default; two full passes over the inputs):
+//       sample  : one workgroup per (key, delta) sorts 4096 sampled |delta| in LDS and picks a bracket [lo, hi] of bit
+//                 patterns around the sample's estimate of the kth value (keys of <= 4096 elements are solved here)
+//       count   : ONE pass over the inputs: exact counts of |delta| < lo and == lo in registers, and a 2048-bin
+//                 LDS histogram of the few elements inside (lo, hi]
+//       resolve : per (key, delta): kth is below the bracket / at lo / in bin b / above.  A bin one bit pattern wide is
+//                 an exact threshold; otherwise the bin is "ambiguous" (expected ~4e-5 of the elements)
+//       merge   : the fused merge pass with the provisional threshold = lower edge of the ambiguous bin; elements that
+//                 fall inside an ambiguous bin are also appended to a small list
+//       select  : per (key, delta) exact radix select of the remaining rank inside its list -> final threshold
+//       fixup   : outputs of listed elements that turn out to lie below the final threshold are recomputed
+//     Brackets that miss (kth outside [lo, hi], or an over-full bin: heavy ties) fall back, per (key, delta), to B; the
+//     fallback kernels are always enqueued and exit at once when a device counter says nothing failed (no host sync).
+//  B. radix select (fallback, and the DARE path): hist<1> -> scan<1> -> hist<2> -> scan<2> -> hist<3> -> scan<3>,
+//     most-significant-digit radix select on the fp32 bit pattern of |delta| (31 value bits split 11 / 11 / 9), LDS
+//     histograms flushed with one global atomic per non-empty bin; three more passes over the inputs.
 //
-// Storage dtypes are runtime (wave-uniform switches around the 16-byte loads and stores); what is
-// compiled in is the register capacity CAP (deltas held per lane: 2, 4 or 8) and the DARE mask path.
+// merge recomputes the deltas, applies |delta| >= threshold, elects the sign, averages the agreeing deltas, and fuses
+// add_difference + output cast + finite checks.  No fp32 delta is ever written to memory.
+// Roofline: HBM.  Algorithmic bytes per element for the fused graph = in_size * (n_models + 1) + out_size (SURVEY.md
+// §8d: 10 B for base + 3 models in bf16); the count pass re-reads the inputs (implementation traffic).
+//
+// Storage dtypes are runtime (wave-uniform switches around the 16-byte loads and stores); what is compiled in is the
+// register capacity CAP (deltas held per lane: 2, 4 or 8) and the DARE mask path.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -27,14 +38,27 @@ namespace {
 
 constexpr int TIES_TILE = 4096;            // elements per tile: 256 lanes x 8 elements x 2 vectors
 constexpr int TIES_BINS = 2048;
-constexpr int TIES_GROUP = 8;              // most deltas handled per hist launch (LDS: 8 x 2048 x 4 B = 64 KiB)
+constexpr int TIES_GROUP = 8;              // most deltas handled per hist/count launch (LDS: 8 x 2048 x 4 B = 64 KiB)
 constexpr int TIES_MAX_DELTAS = MECHA_MAX_MODELS;
+constexpr int TIES_SAMPLE = 4096;          // sampled elements per (key, delta); keys up to this size are sorted whole
+constexpr int AMB_BASE_CAP = 512;          // ambiguous-list capacity per (key, delta) = AMB_BASE_CAP + numel / AMB_DIV
+constexpr int AMB_DIV = 2048;
 
-struct SelectState {                       // per (key, delta)
-    uint32_t prefix;                       // digits selected so far, in place
+enum : uint32_t { MODE_RESOLVED = 0, MODE_AMBIG = 1, MODE_FAILED = 2, MODE_PENDING = 3 };
+
+struct SelectState {                       // per (key, delta), 64 bytes
+    uint32_t prefix;                       // B: digits selected so far, in place
     uint32_t threshold_bits;               // final: fp32 bit pattern of the threshold
-    unsigned long long kth_rem;            // rank still to find inside the matching prefix (1-indexed)
+    unsigned long long kth_rem;            // B: rank still to find inside the matching prefix (1-indexed)
+    unsigned long long kth;                // rank of the threshold among |delta| (1-indexed)
+    uint32_t mode;
+    uint32_t lo, hi, shift;                // A: bracket (inclusive bit patterns) and bin shift
+    uint32_t amb_lo, amb_hi;               // A: the ambiguous bin (inclusive)
+    uint32_t amb_rank, amb_count;          // A: rank inside the bin (1-indexed), elements in it
+    unsigned long long amb_offset;         // A: first slot of this pair's ambiguous list
 };
+struct SelectCounts { unsigned long long below, eq_lo; };
+struct TiesGlobals { uint32_t n_failed; uint32_t pad; unsigned long long n_amb; unsigned long long n_hit; };
 
 struct TiesParams {
     const void *base;                      // nullptr: inputs are deltas
@@ -51,7 +75,20 @@ struct TiesParams {
     long long total_tiles;
     SelectState *state;                    // [n_segs * n_deltas]
     uint32_t *hist;                        // [n_segs * n_deltas * TIES_BINS]
+    // bracket select
+    int bracket;                           // 1: pipeline A is running (the radix kernels then serve only MODE_FAILED pairs)
+    SelectCounts *counts;                  // [n_segs * n_deltas]
+    uint32_t *fill;                        // [n_segs * n_deltas] slots used in each ambiguous list
+    TiesGlobals *globals;
+    long long *amb_elem;                   // ambiguous lists: element index inside the arena / tensor
+    uint32_t *amb_bits;                    //                  |delta| bit pattern
+    uint32_t *amb_sd;                      //                  owning (key, delta) pair
+    long long *hit_elem;                   // hit queue: first element of a vector that held an ambiguous value
+    uint32_t *hit_seg;                     //            its key
+    unsigned long long amb_capacity;       // slots in each of the five arrays above
 };
+
+__device__ __forceinline__ mecha_segment get_segment(const TiesParams &p, int s) { return p.segs == nullptr ? p.seg0 : p.segs[s]; }
 
 // A block walks a contiguous range of tiles; the cursor remembers the key the current tile belongs to
 // and only searches again when the walk leaves that key.
@@ -78,9 +115,9 @@ __device__ __forceinline__ void cursor_seek(const TiesParams &p, long long t, Ti
 // 8 consecutive elements as fp32, dtype chosen at run time (wave-uniform).
 __device__ __forceinline__ void load_rt(int dt, bool vec, const void *ptr, int64_t e, int valid, float (&v)[8]) {
     if (vec) {
-        if (dt == MECHA_BF16) load8<MECHA_BF16>(ptr, e, v);
-        else if (dt == MECHA_F16) load8<MECHA_F16>(ptr, e, v);
-        else load8<MECHA_F32>(ptr, e, v);
+        if (dt == MECHA_BF16) load8<MECHA_BF16, true>(ptr, e, v);      // streamed: far larger than any cache between passes
+        else if (dt == MECHA_F16) load8<MECHA_F16, true>(ptr, e, v);
+        else load8<MECHA_F32, true>(ptr, e, v);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -90,20 +127,23 @@ __device__ __forceinline__ void load_rt(int dt, bool vec, const void *ptr, int64
         }
     }
 }
+__device__ __forceinline__ float load1_rt(int dt, const void *ptr, int64_t e) {
+    return (dt == MECHA_BF16) ? load1<MECHA_BF16>(ptr, e) : (dt == MECHA_F16) ? load1<MECHA_F16>(ptr, e) : load1<MECHA_F32>(ptr, e);
+}
+__device__ __forceinline__ void store1_rt(int dt, void *ptr, int64_t e, float v) {
+    if (dt == MECHA_BF16) store1<MECHA_BF16>(ptr, e, v);
+    else if (dt == MECHA_F16) store1<MECHA_F16>(ptr, e, v);
+    else store1<MECHA_F32>(ptr, e, v);
+}
 __device__ __forceinline__ void store_rt(int dt, bool vec, void *ptr, int64_t e, int valid, const float (&v)[8]) {
     if (vec) {
-        if (dt == MECHA_BF16) store8<MECHA_BF16>(ptr, e, v);
-        else if (dt == MECHA_F16) store8<MECHA_F16>(ptr, e, v);
-        else store8<MECHA_F32>(ptr, e, v);
+        if (dt == MECHA_BF16) store8<MECHA_BF16, true>(ptr, e, v);
+        else if (dt == MECHA_F16) store8<MECHA_F16, true>(ptr, e, v);
+        else store8<MECHA_F32, true>(ptr, e, v);
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j < valid) {
-                if (dt == MECHA_BF16) store1<MECHA_BF16>(ptr, e + j, v[j]);
-                else if (dt == MECHA_F16) store1<MECHA_F16>(ptr, e + j, v[j]);
-                else store1<MECHA_F32>(ptr, e + j, v[j]);
-            }
-        }
+        for (int j = 0; j < 8; j++)
+            if (j < valid) store1_rt(dt, ptr, e + j, v[j]);
     }
 }
 
@@ -115,7 +155,297 @@ __device__ __forceinline__ void apply_keep_bits(const TiesParams &p, int m, int6
     for (int j = 0; j < 8; j++) v[j] = v[j] * (((bits8 >> j) & 1u) ? 1.0f : 0.0f);
 }
 
-// ------------------------------------------------------------------------------------------------ hist
+__device__ __forceinline__ unsigned long long ties_kth(double one_minus_k, int64_t numel) {
+    long long kth = (long long)(one_minus_k * (double)numel);       // max(int((1 - k) * numel), 1)  (ties.py:129)
+    return (unsigned long long)(kth < 1 ? 1 : kth);
+}
+
+// ------------------------------------------------------------------------------------------------ A: sample
+// One workgroup per (key, delta): sort TIES_SAMPLE sampled |delta| bit patterns, derive the bracket.
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, double one_minus_k, float *thresholds_out) {
+    __shared__ uint32_t keys[TIES_SAMPLE];
+    const int64_t sd = blockIdx.x;
+    const int s = (int)(sd / p.n_deltas), d = (int)(sd % p.n_deltas);
+    const mecha_segment seg = get_segment(p, s);
+    const bool whole = seg.numel <= TIES_SAMPLE;
+    if (whole) {
+        for (int idx = threadIdx.x; idx < TIES_SAMPLE; idx += MECHA_BLOCK) {
+            uint32_t bits = 0xffffffffu;                                  // padding sorts last
+            if (idx < seg.numel) {
+                float x = load1_rt(p.in_dt, p.in[d], seg.offset + idx);
+                if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, seg.offset + idx);
+                bits = __float_as_uint(x) & 0x7fffffffu;
+            }
+            keys[idx] = bits;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int vpos = 2 * threadIdx.x + u;                         // 512 stratified runs of 8 contiguous elements
+            const int64_t local = (int64_t)(((unsigned long long)vpos * (unsigned long long)seg.numel) / 512ull) & ~7ll;
+            const int64_t e = seg.offset + local;
+            float v[8], b[8];
+            load_rt(p.in_dt, p.vec_ok != 0, p.in[d], e, 8, v);
+            if (p.base != nullptr) {
+                load_rt(p.in_dt, p.vec_ok != 0, p.base, e, 8, b);
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) keys[vpos * 8 + j] = __float_as_uint(v[j]) & 0x7fffffffu;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= TIES_SAMPLE; k <<= 1) {                          // bitonic sort, ascending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = threadIdx.x; idx < TIES_SAMPLE; idx += MECHA_BLOCK) {
+                const int ixj = idx ^ j;
+                if (ixj > idx) {
+                    const uint32_t a = keys[idx], b = keys[ixj];
+                    const bool up = (idx & k) == 0;
+                    if ((a > b) == up) { keys[idx] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        SelectState st{};
+        st.kth = ties_kth(one_minus_k, seg.numel);
+        if (whole) {
+            st.mode = MODE_RESOLVED;
+            st.threshold_bits = keys[st.kth - 1];
+            if (thresholds_out != nullptr) thresholds_out[sd] = __uint_as_float(st.threshold_bits);
+        } else {
+            const double q = ((double)st.kth - 0.5) / (double)seg.numel;
+            const double r = q * TIES_SAMPLE;
+            const double margin = 6.0 * sqrt(TIES_SAMPLE * q * (1.0 - q)) + 16.0;
+            const long long lo_rank = (long long)floor(r - margin), hi_rank = (long long)ceil(r + margin);
+            st.mode = MODE_PENDING;
+            st.lo = (lo_rank < 0) ? 0u : keys[lo_rank];
+            st.hi = (hi_rank >= TIES_SAMPLE) ? 0x7f800000u : keys[hi_rank];
+            if (st.hi > 0x7f800000u) st.hi = 0x7f800000u;                 // NaN patterns stay above every bracket
+            if (st.lo > st.hi) st.lo = st.hi;
+            // bins over lo <= bits <= hi, see bracket_bin(): 1024 cells of 2^shift patterns, two bins per cell
+            const uint32_t span = st.hi - st.lo;
+            st.shift = (span >= 1024u) ? (uint32_t)(32 - __clz((int)span)) - 10u : 0u;      // span < 2^(shift + 10)
+            const unsigned long long top = ((((unsigned long long)(st.lo >> st.shift)) + 1024ull) << st.shift) - 1ull;
+            if (top < st.hi) st.hi = (uint32_t)top;                       // trims less than one cell off the bracket
+        }
+        p.state[sd] = st;
+        p.counts[sd] = SelectCounts{0ull, 0ull};
+        p.fill[sd] = 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ A: count
+// Bin of a bit pattern inside the bracket (lo <= bits <= hi).  The bracket is cut into 1024 cells of 2^shift patterns,
+// aligned to absolute multiples of 2^shift.  Each cell owns two bins, in value order: bin 2q holds the one pattern
+// whose low `shift` bits are zero, bin 2q + 1 the rest of the cell.  Deltas of half-precision weights are multiples
+// of a coarse power of two, so nearly all the mass (and the kth value) sits on patterns with many trailing zero bits:
+// those get a bin of their own, which is an exact threshold however many elements tie there, while the odd bins
+// collect only the sparse remainder, few enough for the ambiguous list.
+__device__ __forceinline__ uint32_t bracket_bin(uint32_t bits, uint32_t lo, uint32_t shift) {
+    const uint32_t q = (bits >> shift) - (lo >> shift);
+    return 2u * q + ((bits & ((1u << shift) - 1u)) != 0u ? 1u : 0u);
+}
+
+template <int CAP>
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, int d0, int nd) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * TIES_BINS words, then 2 * CAP counters
+    uint32_t *lds_cnt = lds_hist + nd * TIES_BINS;
+    for (int i = threadIdx.x; i < nd * TIES_BINS + 2 * CAP; i += MECHA_BLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
+    const long long t0 = (long long)blockIdx.x * chunk;
+    const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
+    TileCursor cur;
+    uint32_t lo[CAP], shift[CAP];
+    float lo_f[CAP], hi_f[CAP];
+    uint32_t below[CAP];                           // per wave (uniform): elements with |delta| < lo
+    bool active[CAP];
+#pragma unroll
+    for (int d = 0; d < CAP; d++) { below[d] = 0; active[d] = false; lo[d] = shift[d] = 0; lo_f[d] = hi_f[d] = 0.0f; }
+
+    auto flush = [&](int s) {
+#pragma unroll
+        for (int d = 0; d < CAP; d++) {
+            if (d < nd && active[d] && below[d] && (threadIdx.x & 63) == 0) atomicAdd(&lds_cnt[2 * d], below[d]);
+            below[d] = 0;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nd * TIES_BINS; i += MECHA_BLOCK) {
+            const uint32_t c = lds_hist[i];
+            if (c) {
+                const int d = i / TIES_BINS, b = i % TIES_BINS;
+                atomicAdd(p.hist + ((int64_t)s * p.n_deltas + d0 + d) * TIES_BINS + b, c);
+                lds_hist[i] = 0;
+            }
+        }
+        if (threadIdx.x < 2 * nd) {
+            const uint32_t c = lds_cnt[threadIdx.x];
+            if (c) {
+                SelectCounts *sc = p.counts + (int64_t)s * p.n_deltas + d0 + (threadIdx.x >> 1);
+                atomicAdd((threadIdx.x & 1) ? &sc->eq_lo : &sc->below, (unsigned long long)c);
+                lds_cnt[threadIdx.x] = 0;
+            }
+        }
+        __syncthreads();
+    };
+
+    for (long long t = t0; t < t1; t++) {
+        const int prev = cur.s;
+        cursor_seek(p, t, cur);
+        if (cur.s != prev) {
+            if (prev >= 0) flush(prev);
+#pragma unroll
+            for (int d = 0; d < CAP; d++) {
+                if (d < nd) {
+                    const SelectState &st = p.state[(int64_t)cur.s * p.n_deltas + d0 + d];
+                    active[d] = st.mode == MODE_PENDING;
+                    lo[d] = st.lo; shift[d] = st.shift;
+                    lo_f[d] = __uint_as_float(st.lo); hi_f[d] = __uint_as_float(st.hi);     // hi <= +inf: ordered compares
+                }
+            }
+        }
+        bool any = false;
+#pragma unroll
+        for (int d = 0; d < CAP; d++) any |= (d < nd) && active[d];
+        if (!any) continue;                                          // every pair of this key was solved by the sample
+        const mecha_segment seg = cur.seg;
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+            const int64_t local = (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
+            if (local >= seg.numel) continue;
+            const int valid = (seg.numel - local >= 8) ? 8 : (int)(seg.numel - local);
+            const bool vec = p.vec_ok && valid == 8;
+            const int64_t e = seg.offset + local;
+            float b[8];
+            if (p.base != nullptr) load_rt(p.in_dt, vec, p.base, e, valid, b);
+            float v[CAP][8];
+#pragma unroll
+            for (int d = 0; d < CAP; d++)
+                if (d < nd && active[d]) load_rt(p.in_dt, vec, p.in[d0 + d], e, valid, v[d]);
+#pragma unroll
+            for (int d = 0; d < CAP; d++) {
+                if (d < nd && active[d]) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        float x = (p.base != nullptr) ? v[d][j] - b[j] : v[d][j];           // subtract (linear.py:101)
+                        if (valid < 8 && j >= valid) x = __uint_as_float(0x7fffffffu);        // past the key: neither below nor inside
+                        // positive floats order like their bit patterns; NaN compares false twice = above the bracket
+                        const bool is_below = __builtin_fabsf(x) < lo_f[d];
+                        const bool le_hi = __builtin_fabsf(x) <= hi_f[d];
+                        below[d] += (uint32_t)__popcll(__ballot(is_below));
+                        if (le_hi && !is_below)
+                            atomicAdd(&lds_hist[d * TIES_BINS + bracket_bin(__float_as_uint(x) & 0x7fffffffu, lo[d], shift[d])], 1u);
+                    }
+                }
+            }
+        }
+    }
+    if (cur.s >= 0) flush(cur.s);
+}
+
+// ------------------------------------------------------------------------------------------------ A: resolve
+// exclusive prefix of the 2048 bins over the block; returns (bin, count below it) of the bin holding `rank`, bin = -1 if none
+__device__ __forceinline__ void find_bin(const uint32_t *h, unsigned long long rank, int &bin_out, unsigned long long &below_out,
+                                         uint32_t &count_out, unsigned long long *wave_tot, int *sel, unsigned long long *sel_below,
+                                         uint32_t *sel_count) {
+    constexpr int PER = TIES_BINS / MECHA_BLOCK;
+    uint32_t c[PER];
+    unsigned long long local = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { c[j] = h[threadIdx.x * PER + j]; local += c[j]; }
+    unsigned long long incl = local;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    if (threadIdx.x == 0) *sel = -1;
+    __syncthreads();
+    unsigned long long before = incl - local;
+    for (int w = 0; w < wave; w++) before += wave_tot[w];
+    if (rank > before && rank <= before + local) {                  // exactly one thread's bin range contains the rank
+        unsigned long long cum = before;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (rank > cum && rank <= cum + c[j]) { *sel = threadIdx.x * PER + j; *sel_below = cum; *sel_count = c[j]; }
+            cum += c[j];
+        }
+    }
+    __syncthreads();
+    bin_out = *sel; below_out = *sel_below; count_out = *sel_count;
+}
+
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_resolve_kernel(TiesParams p, float *thresholds_out, int force_fail) {
+    __shared__ unsigned long long wave_tot[MECHA_BLOCK / 64];
+    __shared__ int sel;
+    __shared__ unsigned long long sel_below;
+    __shared__ uint32_t sel_count;
+    const int64_t sd = blockIdx.x;
+    SelectState st = p.state[sd];
+    if (st.mode != MODE_PENDING) return;
+    uint32_t *h = p.hist + sd * TIES_BINS;
+    const SelectCounts sc = p.counts[sd];
+    const int s = (int)(sd / p.n_deltas);
+    const int64_t numel = get_segment(p, s).numel;
+    const unsigned long long cap = (unsigned long long)AMB_BASE_CAP + (unsigned long long)numel / AMB_DIV;
+    uint32_t mode = MODE_FAILED;
+    int bin = -1; unsigned long long below = 0; uint32_t count = 0;
+    if (!force_fail && st.kth > sc.below) {
+        if (st.kth <= sc.below + sc.eq_lo) { mode = MODE_RESOLVED; st.threshold_bits = st.lo; }
+        else {
+            find_bin(h, st.kth - sc.below - sc.eq_lo, bin, below, count, wave_tot, &sel, &sel_below, &sel_count);
+            if (bin >= 0) {
+                const uint32_t cell = (((st.lo >> st.shift) + ((uint32_t)bin >> 1)) << st.shift);   // see bracket_bin()
+                if ((bin & 1) == 0) { mode = MODE_RESOLVED; st.threshold_bits = cell; }
+                else {
+                    st.amb_lo = (cell + 1u > st.lo) ? cell + 1u : st.lo;
+                    const unsigned long long top = (unsigned long long)cell + ((1ull << st.shift) - 1ull);
+                    st.amb_hi = (top > st.hi) ? st.hi : (uint32_t)top;
+                    st.amb_rank = (uint32_t)(st.kth - sc.below - sc.eq_lo - below);
+                    st.amb_count = count;
+                    if (st.amb_lo == st.amb_hi) { mode = MODE_RESOLVED; st.threshold_bits = st.amb_lo; }
+                    else if (count <= cap) mode = MODE_AMBIG;
+                }
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < TIES_BINS; i += MECHA_BLOCK) h[i] = 0;      // ready for the fallback / the next call
+    if (threadIdx.x == 0) {
+        st.mode = mode;
+        if (mode == MODE_RESOLVED && thresholds_out != nullptr) thresholds_out[sd] = __uint_as_float(st.threshold_bits);
+        if (mode == MODE_FAILED) atomicAdd(&p.globals->n_failed, 1u);
+        p.state[sd] = st;
+    }
+}
+
+// amb_offset = exclusive prefix of amb_count over the ambiguous pairs (one block)
+__global__ __launch_bounds__(1024) void ties_amb_offsets_kernel(TiesParams p, int64_t n_sd) {
+    __shared__ unsigned long long part[1024];
+    const int64_t per = (n_sd + 1023) / 1024;
+    const int64_t lo = (threadIdx.x * per < n_sd) ? threadIdx.x * per : n_sd, hi = (lo + per < n_sd) ? lo + per : n_sd;
+    unsigned long long sum = 0;
+    for (int64_t i = lo; i < hi; i++) sum += (p.state[i].mode == MODE_AMBIG) ? p.state[i].amb_count : 0u;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; i++) { unsigned long long v = part[i]; part[i] = run; run += v; }
+        p.globals->n_amb = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int64_t i = lo; i < hi; i++) {
+        if (p.state[i].mode == MODE_AMBIG) { p.state[i].amb_offset = run; run += p.state[i].amb_count; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B: hist / scan
 template <int PASS> struct PassCfg;
 template <> struct PassCfg<1> { static constexpr int shift = 20, bins = 2048; static constexpr uint32_t prefix_mask = 0u; };
 template <> struct PassCfg<2> { static constexpr int shift = 9, bins = 2048; static constexpr uint32_t prefix_mask = 0x7ff00000u; };
@@ -124,6 +454,7 @@ template <> struct PassCfg<3> { static constexpr int shift = 0, bins = 512; stat
 template <int PASS, int CAP, bool DARE>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, int d0, int nd) {
     using C = PassCfg<PASS>;
+    if (p.bracket && p.globals->n_failed == 0) return;             // nothing fell back
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * TIES_BINS words
     for (int i = threadIdx.x; i < nd * TIES_BINS; i += MECHA_BLOCK) lds_hist[i] = 0;
     __syncthreads();
@@ -132,7 +463,6 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
     const long long t0 = (long long)blockIdx.x * chunk;
     const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
     TileCursor cur;
-    int flushed_seg = -1;
 
     auto flush = [&](int s) {
         __syncthreads();
@@ -148,17 +478,27 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
     };
 
     uint32_t want[CAP];
+    bool active[CAP];
+#pragma unroll
+    for (int d = 0; d < CAP; d++) { want[d] = 0; active[d] = false; }
     for (long long t = t0; t < t1; t++) {
         const int prev = cur.s;
         cursor_seek(p, t, cur);
         if (cur.s != prev) {
             if (prev >= 0) flush(prev);
-            flushed_seg = prev;
-            if constexpr (PASS > 1) {
 #pragma unroll
-                for (int d = 0; d < CAP; d++) want[d] = (d < nd) ? p.state[(int64_t)cur.s * p.n_deltas + d0 + d].prefix : 0u;
+            for (int d = 0; d < CAP; d++) {
+                if (d < nd) {
+                    const SelectState &st = p.state[(int64_t)cur.s * p.n_deltas + d0 + d];
+                    active[d] = !p.bracket || st.mode == MODE_FAILED;
+                    if constexpr (PASS > 1) want[d] = st.prefix;
+                }
             }
         }
+        bool any = false;
+#pragma unroll
+        for (int d = 0; d < CAP; d++) any |= (d < nd) && active[d];
+        if (!any) continue;
         const mecha_segment seg = cur.seg;
 #pragma unroll 1
         for (int u = 0; u < 2; u++) {
@@ -172,10 +512,10 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
             float v[CAP][8];
 #pragma unroll
             for (int d = 0; d < CAP; d++)
-                if (d < nd) load_rt(p.in_dt, vec, p.in[d0 + d], e, valid, v[d]);
+                if (d < nd && active[d]) load_rt(p.in_dt, vec, p.in[d0 + d], e, valid, v[d]);
 #pragma unroll
             for (int d = 0; d < CAP; d++) {
-                if (d < nd) {
+                if (d < nd && active[d]) {
                     if (p.base != nullptr) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) v[d][j] = v[d][j] - b[j];              // subtract (linear.py:101)
@@ -192,65 +532,37 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
             }
         }
     }
-    (void)flushed_seg;
     if (cur.s >= 0) flush(cur.s);
 }
 
-// ------------------------------------------------------------------------------------------------ scan
 // One block per (key, delta): find the bin holding rank kth_rem, update the state, zero the histogram.
 template <int PASS>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_scan_kernel(TiesParams p, double one_minus_k, float *thresholds_out) {
     using C = PassCfg<PASS>;
     __shared__ unsigned long long wave_tot[MECHA_BLOCK / 64];
-    __shared__ int sel_bin;
+    __shared__ int sel;
     __shared__ unsigned long long sel_below;
-    const int64_t sd = blockIdx.x;                              // s * n_deltas + d
+    __shared__ uint32_t sel_count;
+    if (p.bracket && p.globals->n_failed == 0) return;
+    const int64_t sd = blockIdx.x;
     const int s = (int)(sd / p.n_deltas);
     uint32_t *h = p.hist + sd * TIES_BINS;
     SelectState st = p.state[sd];
+    if (p.bracket && st.mode != MODE_FAILED) return;
     if constexpr (PASS == 1) {
-        const mecha_segment seg = (p.segs == nullptr) ? p.seg0 : p.segs[s];
-        long long kth = (long long)(one_minus_k * (double)seg.numel);   // max(int((1 - k) * numel), 1)  (ties.py:129)
-        if (kth < 1) kth = 1;
-        st.prefix = 0; st.threshold_bits = 0; st.kth_rem = (unsigned long long)kth;
+        st.kth = ties_kth(one_minus_k, get_segment(p, s).numel);
+        st.prefix = 0; st.threshold_bits = 0; st.kth_rem = st.kth;
     }
-    constexpr int PER = TIES_BINS / MECHA_BLOCK;                // 8 bins per thread, contiguous
-    uint32_t c[PER];
-    unsigned long long local = 0;
-#pragma unroll
-    for (int j = 0; j < PER; j++) { c[j] = h[threadIdx.x * PER + j]; local += c[j]; }
-    // exclusive prefix over threads: wave scan, then wave totals
-    unsigned long long incl = local;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned long long n = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += n;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    if (threadIdx.x == 0) sel_bin = -1;
-    __syncthreads();
-    unsigned long long before = incl - local;
-    for (int w = 0; w < wave; w++) before += wave_tot[w];
-    // exactly one thread's bin range contains rank kth_rem
-    if (st.kth_rem > before && st.kth_rem <= before + local) {
-        unsigned long long cum = before;
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            if (st.kth_rem > cum && st.kth_rem <= cum + c[j]) { sel_bin = threadIdx.x * PER + j; sel_below = cum; }
-            cum += c[j];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; j++) h[threadIdx.x * PER + j] = 0;   // ready for the next pass / the next call
+    int bin; unsigned long long below; uint32_t count;
+    find_bin(h, st.kth_rem, bin, below, count, wave_tot, &sel, &sel_below, &sel_count);
+    for (int i = threadIdx.x; i < TIES_BINS; i += MECHA_BLOCK) h[i] = 0;     // ready for the next pass / the next call
     if (threadIdx.x == 0) {
-        int bin = sel_bin;
-        if (bin < 0) { bin = 0; sel_below = 0; }                 // unreachable for kth <= numel; keeps the state defined
+        if (bin < 0) { bin = 0; below = 0; }                     // unreachable for kth <= numel; keeps the state defined
         st.prefix |= ((uint32_t)bin) << C::shift;
-        st.kth_rem -= sel_below;
+        st.kth_rem -= below;
         if constexpr (PASS == 3) {
             st.threshold_bits = st.prefix;
+            st.mode = MODE_RESOLVED;
             if (thresholds_out != nullptr) thresholds_out[sd] = __uint_as_float(st.prefix);
         }
         p.state[sd] = st;
@@ -267,6 +579,40 @@ struct MergeExtra {
 
 __device__ __forceinline__ float sign_f(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }   // torch.sign: sign(+-0) = 0
 
+// provisional threshold of a pair: the final one, or the lower edge of its ambiguous bin
+__device__ __forceinline__ float prov_threshold(const SelectState &st) {
+    return __uint_as_float(st.mode == MODE_AMBIG ? st.amb_lo : st.threshold_bits);
+}
+
+// The merge pass only notes WHICH 8-element vectors held a value inside an ambiguous bin (hit queue: a handful of
+// entries per key).  This kernel re-reads those vectors and appends the ambiguous values to their pairs' lists.
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_collect_kernel(TiesParams p) {
+    const unsigned long long n = p.globals->n_hit < p.amb_capacity ? p.globals->n_hit : p.amb_capacity;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * MECHA_BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * MECHA_BLOCK) {
+        const int s = (int)p.hit_seg[i];
+        const int64_t e = p.hit_elem[i];
+        const mecha_segment seg = get_segment(p, s);
+        const int64_t left = seg.offset + seg.numel - e;
+        const int valid = left >= 8 ? 8 : (int)left;
+        for (int m = 0; m < p.n_deltas; m++) {
+            const int64_t sd = (int64_t)s * p.n_deltas + m;
+            const SelectState &st = p.state[sd];
+            if (st.mode != MODE_AMBIG) continue;
+            for (int j = 0; j < valid; j++) {
+                float x = load1_rt(p.in_dt, p.in[m], e + j);
+                if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, e + j);
+                const uint32_t bits = __float_as_uint(x) & 0x7fffffffu;
+                if (bits < st.amb_lo || bits > st.amb_hi) continue;
+                const uint32_t slot = atomicAdd(&p.fill[sd], 1u);
+                if (slot >= st.amb_count) continue;              // cannot happen: the count pass saw the same elements
+                const unsigned long long at = st.amb_offset + slot;
+                if (at >= p.amb_capacity) continue;
+                p.amb_elem[at] = e + j; p.amb_bits[at] = bits; p.amb_sd[at] = (uint32_t)sd;
+            }
+        }
+    }
+}
+
 template <int CAP, bool DARE>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
     const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
@@ -275,13 +621,21 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
     const bool in_regs = p.n_deltas <= CAP;        // one sweep over the inputs; otherwise the second sweep re-reads them
     TileCursor cur;
     float thr[CAP];
+    float amb_hi[CAP];                             // upper edge of the ambiguous bin as a float, -1 = none
+#pragma unroll
+    for (int d = 0; d < CAP; d++) { thr[d] = 0.0f; amb_hi[d] = -1.0f; }
     for (long long t = t0; t < t1; t++) {
         const int prev = cur.s;
         cursor_seek(p, t, cur);
         const SelectState *st = p.state + (int64_t)cur.s * p.n_deltas;
         if (cur.s != prev && in_regs) {
 #pragma unroll
-            for (int d = 0; d < CAP; d++) thr[d] = (d < p.n_deltas) ? __uint_as_float(st[d].threshold_bits) : 0.0f;
+            for (int d = 0; d < CAP; d++) {
+                if (d < p.n_deltas) {
+                    thr[d] = prov_threshold(st[d]);
+                    amb_hi[d] = (st[d].mode == MODE_AMBIG) ? __uint_as_float(st[d].amb_hi) : -1.0f;
+                }
+            }
         }
         const mecha_segment seg = cur.seg;
 #pragma unroll 1
@@ -292,27 +646,35 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             const bool vec = p.vec_ok && valid == 8;
             const int64_t e = seg.offset + local;
             float b[8];
-            bool bad_in = false;
+            float poison = 0.0f;                   // fma(x, 0, poison): stays 0 while every input is finite, NaN after inf / NaN
+            bool hit = false;                      // some |delta| of this lane lies in an ambiguous bin
             if (p.base != nullptr) {
                 load_rt(p.in_dt, vec, p.base, e, valid, b);
 #pragma unroll
-                for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(b[j]);
+                for (int j = 0; j < 8; j++) poison = __builtin_fmaf(b[j], 0.0f, poison);
             }
-            // filtered delta f_m = delta_m * (|delta_m| >= thr_m)   (ties.py:128-132)
-            auto filter = [&](int m, float t_m, float (&f)[8]) {
+            // filtered delta f_m = delta_m * (|delta_m| >= thr_m)   (ties.py:128-132); a select gives the same values
+            // up to the sign of a zero, which neither the vote (sign(+-0) = 0) nor the sums (from +0) can see
+            auto filter = [&](int m, float t_m, float amb_hi_m, float (&f)[8]) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(f[j]);
+                for (int j = 0; j < 8; j++) poison = __builtin_fmaf(f[j], 0.0f, poison);
                 if (p.base != nullptr) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) f[j] = f[j] - b[j];
                 }
                 if constexpr (DARE) apply_keep_bits(p, m, local, f);
 #pragma unroll
-                for (int j = 0; j < 8; j++) f[j] = f[j] * ((__builtin_fabsf(f[j]) >= t_m) ? 1.0f : 0.0f);
+                for (int j = 0; j < 8; j++) {
+                    const float mag = __builtin_fabsf(f[j]);
+                    const bool keep = mag >= t_m;
+                    hit |= keep && (mag <= amb_hi_m);
+                    f[j] = keep ? f[j] : 0.0f;
+                }
             };
-            float vote[8], acc[8], cnt[8];
+            float vote[8], acc[8];                 // vote: an fp32 sum (vote_sgn) or an integer count kept in the same registers
+            int cnt[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) { vote[j] = 0.0f; acc[j] = 0.0f; cnt[j] = 0.0f; }
+            for (int j = 0; j < 8; j++) { vote[j] = 0.0f; acc[j] = 0.0f; cnt[j] = 0; }
             float f[CAP][8];
             // sweep 1: the vote  (ties.py:120: sum of signs, or of deltas if vote_sgn), index order from +0
             for (int g = 0; g < p.n_deltas; g += CAP) {
@@ -322,22 +684,38 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
 #pragma unroll
                 for (int d = 0; d < CAP; d++)
                     if (g + d < p.n_deltas) {
-                        filter(g + d, in_regs ? thr[d] : __uint_as_float(st[g + d].threshold_bits), f[d]);
+                        if (in_regs) filter(g + d, thr[d], amb_hi[d], f[d]);
+                        else filter(g + d, prov_threshold(st[g + d]), (st[g + d].mode == MODE_AMBIG) ? __uint_as_float(st[g + d].amb_hi) : -1.0f, f[d]);
+                        if (x.vote_sgn) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) vote[j] += x.vote_sgn ? f[d][j] : sign_f(f[d][j]);
+                            for (int j = 0; j < 8; j++) vote[j] += f[d][j];
+                        } else {
+                            // sign(f) as an integer: clamp the bit pattern of f + 0 (the add turns -0 into +0) to [-1, 1]
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const int sb = (int)__float_as_uint(f[d][j] + 0.0f);
+                                vote[j] = __int_as_float(__float_as_int(vote[j]) + (sb > 1 ? 1 : (sb < -1 ? -1 : sb)));
+                            }
+                        }
                     }
             }
             float fs[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) fs[j] = sign_f(vote[j]);
-            // sweep 2: disjoint mean over the deltas whose sign agrees (ties.py:122-124, :110)
+            for (int j = 0; j < 8; j++) {
+                const int vi = __float_as_int(vote[j]);
+                fs[j] = x.vote_sgn ? sign_f(vote[j]) : (float)((vi > 0) - (vi < 0));
+            }
+            // sweep 2: disjoint mean over the deltas whose sign agrees (ties.py:122-124, :110).  g = f * fs is positive
+            // exactly for the agreeing non-zero deltas; summing |f| = g and restoring the sign afterwards rounds like
+            // the signed sum.  fs = 0 (agreeing deltas are the zeros) gives 0 / 0 -> nan_to_num -> 0 like the reference's
+            // 0 / count.
             for (int g = 0; g < p.n_deltas; g += CAP) {
                 if (!in_regs) {
 #pragma unroll
                     for (int d = 0; d < CAP; d++)
                         if (g + d < p.n_deltas) {
                             load_rt(p.in_dt, vec, p.in[g + d], e, valid, f[d]);
-                            filter(g + d, __uint_as_float(st[g + d].threshold_bits), f[d]);
+                            filter(g + d, prov_threshold(st[g + d]), -1.0f, f[d]);
                         }
                 }
 #pragma unroll
@@ -345,17 +723,18 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
                     if (g + d < p.n_deltas) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            const float agree = (sign_f(f[d][j]) == fs[j]) ? 1.0f : 0.0f;
-                            acc[j] += f[d][j] * agree;
-                            cnt[j] += agree;
+                            const float gj = f[d][j] * fs[j];
+                            acc[j] += __builtin_fmaxf(gj, 0.0f);
+                            cnt[j] += gj > 0.0f;
                         }
                     }
             }
+            const bool bad_in = poison != poison;
             float r[8];
             bool bad_out = false;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                float q = acc[j] / cnt[j];
+                float q = (acc[j] * fs[j]) / (float)cnt[j];
                 if (nonfinite_f32(q)) q = 0.0f;                                     // nan_to_num(nan=0, posinf=0, neginf=0)
                 if (x.has_rescale) q = q / x.rescale_div;                           // ties.py:50
                 if (p.base != nullptr) q = __builtin_fmaf(q, x.alpha, b[j]);        // base.addcmul(ties, alpha)  (linear.py:76)
@@ -366,7 +745,84 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             if ((bad_in | bad_out) && flags != nullptr)
                 atomicOr(flags + (p.tile_start == nullptr ? 0 : cur.s),
                          (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+            if (hit) {
+                const unsigned long long slot = atomicAdd(&p.globals->n_hit, 1ull);
+                if (slot < p.amb_capacity) { p.hit_elem[slot] = e; p.hit_seg[slot] = (uint32_t)cur.s; }
+            }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ A: select + fixup
+// One block per ambiguous pair: exact radix select (11 / 11 / 10 bits) of rank amb_rank inside its list.
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_select_kernel(TiesParams p, float *thresholds_out) {
+    __shared__ uint32_t hist[TIES_BINS];
+    __shared__ uint32_t s_prefix, s_rank;
+    const int64_t sd = blockIdx.x;
+    const SelectState st = p.state[sd];
+    if (st.mode != MODE_AMBIG) return;
+    const uint32_t n = p.fill[sd] < st.amb_count ? p.fill[sd] : st.amb_count;
+    const uint32_t *bits = p.amb_bits + st.amb_offset;
+    if (threadIdx.x == 0) { s_prefix = 0; s_rank = st.amb_rank; }
+    const int shifts[3] = {21, 10, 0};
+    const uint32_t masks[3] = {0u, 0xffe00000u, 0xfffffc00u};
+    const uint32_t nbins[3] = {2048u, 2048u, 1024u};
+    for (int pass = 0; pass < 3; pass++) {
+        for (int i = threadIdx.x; i < TIES_BINS; i += MECHA_BLOCK) hist[i] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (uint32_t i = threadIdx.x; i < n; i += MECHA_BLOCK) {
+            const uint32_t b = bits[i];
+            if ((b & masks[pass]) == prefix) atomicAdd(&hist[(b >> shifts[pass]) & (nbins[pass] - 1u)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t cum = 0, rank = s_rank, bin = 0;
+            for (uint32_t k = 0; k < nbins[pass]; k++) {
+                if (rank <= cum + hist[k]) { bin = k; break; }
+                cum += hist[k];
+                bin = k;
+            }
+            s_prefix = prefix | (bin << shifts[pass]);
+            s_rank = rank - cum;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.state[sd].threshold_bits = s_prefix;
+        if (thresholds_out != nullptr) thresholds_out[sd] = __uint_as_float(s_prefix);
+    }
+}
+
+// Listed elements whose |delta| is below the final threshold were provisionally kept: recompute their output element.
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_fixup_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
+    const unsigned long long n = p.globals->n_amb < p.amb_capacity ? p.globals->n_amb : p.amb_capacity;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * MECHA_BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * MECHA_BLOCK) {
+        const int64_t sd = p.amb_sd[i];
+        if (p.amb_bits[i] >= p.state[sd].threshold_bits) continue;            // the provisional decision was right
+        const int s = (int)(sd / p.n_deltas);
+        const int64_t e = p.amb_elem[i];
+        const SelectState *st = p.state + (int64_t)s * p.n_deltas;
+        const float b = (p.base != nullptr) ? load1_rt(p.in_dt, p.base, e) : 0.0f;
+        auto filtered = [&](int m) {
+            float f = load1_rt(p.in_dt, p.in[m], e);
+            if (p.base != nullptr) f = f - b;
+            return f * ((__builtin_fabsf(f) >= __uint_as_float(st[m].threshold_bits)) ? 1.0f : 0.0f);
+        };
+        float vote = 0.0f;
+        for (int m = 0; m < p.n_deltas; m++) { const float f = filtered(m); vote += x.vote_sgn ? f : sign_f(f); }
+        const float fs = sign_f(vote);
+        float acc = 0.0f, cnt = 0.0f;
+        for (int m = 0; m < p.n_deltas; m++) {
+            const float f = filtered(m);
+            const float agree = (sign_f(f) == fs) ? 1.0f : 0.0f;
+            acc += f * agree; cnt += agree;
+        }
+        float q = acc / cnt;
+        if (nonfinite_f32(q)) q = 0.0f;
+        if (p.base != nullptr) q = __builtin_fmaf(q, x.alpha, b);
+        store1_rt(p.out_dt, out, e, q);
+        if (nonfinite_f32(q) && flags != nullptr) atomicOr(flags + (p.tile_start == nullptr ? 0 : s), MECHA_FLAG_OUTPUT_NONFINITE);
     }
 }
 
@@ -394,14 +850,26 @@ __global__ __launch_bounds__(1024) void ties_tile_index_kernel(const mecha_segme
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    size_t tile_start_off, state_off, hist_off, total;
+    size_t tile_start_off, state_off, counts_off, fill_off, globals_off, hist_off, amb_elem_off, amb_bits_off, amb_sd_off,
+        hit_elem_off, hit_seg_off, total;
+    size_t amb_capacity;
 };
-WorkspaceLayout layout(int n_deltas, int n_segs) {
+WorkspaceLayout layout(int n_deltas, int n_segs, int64_t total_elems) {
     WorkspaceLayout w;
+    const size_t n_sd = (size_t)n_segs * n_deltas;
+    w.amb_capacity = n_sd * AMB_BASE_CAP + (size_t)n_deltas * ((size_t)(total_elems > 0 ? total_elems : 0) / AMB_DIV + 1);
     size_t off = 0;
     w.tile_start_off = off; off = align_up(off + sizeof(long long) * ((size_t)n_segs + 1), 256);
-    w.state_off = off;      off = align_up(off + sizeof(SelectState) * (size_t)n_segs * n_deltas, 256);
-    w.hist_off = off;       off = align_up(off + sizeof(uint32_t) * (size_t)n_segs * n_deltas * TIES_BINS, 256);
+    w.state_off = off;      off = align_up(off + sizeof(SelectState) * n_sd, 256);
+    w.counts_off = off;     off = align_up(off + sizeof(SelectCounts) * n_sd, 256);
+    w.fill_off = off;       off = align_up(off + sizeof(uint32_t) * n_sd, 256);
+    w.globals_off = off;    off = align_up(off + sizeof(TiesGlobals), 256);
+    w.hist_off = off;       off = align_up(off + sizeof(uint32_t) * n_sd * TIES_BINS, 256);
+    w.amb_elem_off = off;   off = align_up(off + sizeof(long long) * w.amb_capacity, 256);
+    w.amb_bits_off = off;   off = align_up(off + sizeof(uint32_t) * w.amb_capacity, 256);
+    w.amb_sd_off = off;     off = align_up(off + sizeof(uint32_t) * w.amb_capacity, 256);
+    w.hit_elem_off = off;   off = align_up(off + sizeof(long long) * w.amb_capacity, 256);
+    w.hit_seg_off = off;    off = align_up(off + sizeof(uint32_t) * w.amb_capacity, 256);
     w.total = off;
     return w;
 }
@@ -416,6 +884,7 @@ struct TiesCall {
     const mecha_segment *segs_host;         // batched
     int n_segs;
     int64_t numel;                          // per key
+    int64_t total_elems;                    // batched: arena length the workspace was sized for
     int in_dt, out_dt;
     double k;
     float alpha;
@@ -441,9 +910,17 @@ void launch_hist(const TiesParams &p, unsigned grid, hipStream_t s) {
     }
 }
 
+void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
+    for (int d0 = 0; d0 < p.n_deltas; d0 += TIES_GROUP) {
+        const int nd = (p.n_deltas - d0 < TIES_GROUP) ? p.n_deltas - d0 : TIES_GROUP;
+        if (nd <= 2) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<2>), dim3(grid), dim3(MECHA_BLOCK), ((size_t)nd * TIES_BINS + 4) * sizeof(uint32_t), s, p, d0, nd);
+        else if (nd <= 4) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<4>), dim3(grid), dim3(MECHA_BLOCK), ((size_t)nd * TIES_BINS + 8) * sizeof(uint32_t), s, p, d0, nd);
+        else MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<8>), dim3(grid), dim3(MECHA_BLOCK), ((size_t)nd * TIES_BINS + 16) * sizeof(uint32_t), s, p, d0, nd);
+    }
+}
+
 template <bool DARE>
-void launch_all(const TiesParams &p, const MergeExtra &x, unsigned grid, double one_minus_k, float *thresholds_out, void *out,
-                uint32_t *flags, hipStream_t s) {
+void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float *thresholds_out, hipStream_t s) {
     const unsigned scan_grid = (unsigned)((int64_t)p.n_segs * p.n_deltas);
     launch_hist<1, DARE>(p, grid, s);
     MECHA_LAUNCH(MK_TIES_SCAN, (ties_scan_kernel<1>), dim3(scan_grid), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, thresholds_out);
@@ -451,6 +928,10 @@ void launch_all(const TiesParams &p, const MergeExtra &x, unsigned grid, double 
     MECHA_LAUNCH(MK_TIES_SCAN, (ties_scan_kernel<2>), dim3(scan_grid), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, thresholds_out);
     launch_hist<3, DARE>(p, grid, s);
     MECHA_LAUNCH(MK_TIES_SCAN, (ties_scan_kernel<3>), dim3(scan_grid), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, thresholds_out);
+}
+
+template <bool DARE>
+void launch_merge(const TiesParams &p, const MergeExtra &x, unsigned grid, void *out, uint32_t *flags, hipStream_t s) {
     if (p.n_deltas <= 2) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<2, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
     else if (p.n_deltas <= 4) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<4, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
     else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<8, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
@@ -465,6 +946,7 @@ int run_ties(const TiesCall &c) {
     MECHA_REQUIRE(c.k >= 0.0 && c.k <= 1.0, "k must be in [0, 1] (got %g): torch.kthvalue would raise", c.k);
     const bool batched = c.segs_dev != nullptr;
     long long total_tiles = 0;
+    int64_t max_numel = 0, sum_numel = 0;
     if (batched) {
         MECHA_REQUIRE(c.segs_host != nullptr && c.n_segs >= 1, "batched TIES needs host and device segment tables");
         int64_t prev_end = 0;
@@ -473,15 +955,19 @@ int run_ties(const TiesCall &c) {
                           "segment %d: offsets must be multiples of 8, sorted and non-overlapping, numel > 0", s);
             prev_end = c.segs_host[s].offset + c.segs_host[s].numel;
             total_tiles += (c.segs_host[s].numel + TIES_TILE - 1) / TIES_TILE;
+            if (c.segs_host[s].numel > max_numel) max_numel = c.segs_host[s].numel;
+            sum_numel += c.segs_host[s].numel;
         }
+        MECHA_REQUIRE(sum_numel <= c.total_elems, "segments hold %lld elements, more than total_elems = %lld", (long long)sum_numel, (long long)c.total_elems);
     } else {
         MECHA_REQUIRE(c.numel >= 0, "numel must be >= 0");
         total_tiles = (c.numel + TIES_TILE - 1) / TIES_TILE;
+        max_numel = sum_numel = c.numel;
     }
     const int n_segs = batched ? c.n_segs : 1;
     MECHA_REQUIRE(!(c.base != nullptr && mecha_isclose(c.alpha, 0.0)),
                   "alpha == 0: add_difference returns `a` untouched (linear.py:72-73); call the cast entry point on base instead");
-    const WorkspaceLayout w = layout(c.n_deltas, n_segs);
+    const WorkspaceLayout w = layout(c.n_deltas, n_segs, batched ? c.total_elems : c.numel);
     MECHA_REQUIRE(c.workspace != nullptr && c.workspace_bytes >= w.total && mecha_aligned16(c.workspace),
                   "TIES workspace too small or unaligned: need %zu bytes, got %zu", w.total, c.workspace_bytes);
     if (c.keep_bits != nullptr) MECHA_REQUIRE(!batched && c.base == nullptr, "DARE masks are supported on the per-key delta form only");
@@ -493,6 +979,13 @@ int run_ties(const TiesCall &c) {
     }
     hipStream_t s = static_cast<hipStream_t>(c.stream);
     char *ws = static_cast<char *>(c.workspace);
+    const bool dare = c.keep_bits != nullptr;
+    // MECHA_TIES_SELECT=radix forces pipeline B; =fail makes every bracket miss (exercises the per-pair fallback)
+    const char *env = getenv("MECHA_TIES_SELECT");
+    const bool force_radix = env != nullptr && strcmp(env, "radix") == 0;
+    const int force_fail = (env != nullptr && strcmp(env, "fail") == 0) ? 1 : 0;
+    const bool bracket = !dare && !force_radix;
+
     TiesParams p{};
     p.base = c.base;
     for (int m = 0; m < c.n_deltas; m++) p.in[m] = c.inputs[m];
@@ -509,21 +1002,51 @@ int run_ties(const TiesCall &c) {
     p.total_tiles = total_tiles;
     p.state = reinterpret_cast<SelectState *>(ws + w.state_off);
     p.hist = reinterpret_cast<uint32_t *>(ws + w.hist_off);
+    p.bracket = bracket ? 1 : 0;
+    p.counts = reinterpret_cast<SelectCounts *>(ws + w.counts_off);
+    p.fill = reinterpret_cast<uint32_t *>(ws + w.fill_off);
+    p.globals = reinterpret_cast<TiesGlobals *>(ws + w.globals_off);
+    p.amb_elem = reinterpret_cast<long long *>(ws + w.amb_elem_off);
+    p.amb_bits = reinterpret_cast<uint32_t *>(ws + w.amb_bits_off);
+    p.amb_sd = reinterpret_cast<uint32_t *>(ws + w.amb_sd_off);
+    p.hit_elem = reinterpret_cast<long long *>(ws + w.hit_elem_off);
+    p.hit_seg = reinterpret_cast<uint32_t *>(ws + w.hit_seg_off);
+    p.amb_capacity = w.amb_capacity;
 
-    MECHA_CHECK_HIP(hipMemsetAsync(p.hist, 0, sizeof(uint32_t) * (size_t)n_segs * c.n_deltas * TIES_BINS, s));
+    const size_t n_sd = (size_t)n_segs * c.n_deltas;
+    MECHA_REQUIRE(n_sd < ((size_t)1 << 31), "too many (key, delta) pairs");
+    // state, fill, globals are contiguous up to the histograms: one memset clears them all
+    MECHA_CHECK_HIP(hipMemsetAsync(ws + w.state_off, 0, w.amb_elem_off - w.state_off, s));
     if (batched)
         MECHA_LAUNCH(MK_TIES_INDEX, ties_tile_index_kernel, dim3(1), dim3(1024), 0, s, c.segs_dev, n_segs,
                      reinterpret_cast<long long *>(ws + w.tile_start_off));
     unsigned grid = (unsigned)(total_tiles < MECHA_MAX_GRID ? total_tiles : MECHA_MAX_GRID);
     const double one_minus_k = 1.0 - c.k;
-    const bool dare = c.keep_bits != nullptr;
     MergeExtra x{};
     x.alpha = c.alpha;
     x.vote_sgn = c.vote_sgn;
     x.has_rescale = dare && c.rescale;
     x.rescale_div = 1.0f - c.probability;                 // 1.0 - probability as fp32 tensor arithmetic (ties.py:49)
-    if (dare) launch_all<true>(p, x, grid, one_minus_k, c.thresholds_out, c.out, c.flags, s);
-    else launch_all<false>(p, x, grid, one_minus_k, c.thresholds_out, c.out, c.flags, s);
+
+    if (!bracket) {
+        if (dare) { launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s); launch_merge<true>(p, x, grid, c.out, c.flags, s); }
+        else { launch_radix<false>(p, grid, one_minus_k, c.thresholds_out, s); launch_merge<false>(p, x, grid, c.out, c.flags, s); }
+    } else {
+        const bool need_count = max_numel > TIES_SAMPLE;
+        MECHA_LAUNCH(MK_TIES_SAMPLE, ties_sample_kernel, dim3((unsigned)n_sd), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, c.thresholds_out);
+        if (need_count) {
+            launch_count(p, grid, s);
+            MECHA_LAUNCH(MK_TIES_RESOLVE, ties_resolve_kernel, dim3((unsigned)n_sd), dim3(MECHA_BLOCK), 0, s, p, c.thresholds_out, force_fail);
+            launch_radix<false>(p, grid, one_minus_k, c.thresholds_out, s);     // serves MODE_FAILED pairs only; exits at once if there are none
+            MECHA_LAUNCH(MK_TIES_RESOLVE, ties_amb_offsets_kernel, dim3(1), dim3(1024), 0, s, p, (int64_t)n_sd);
+        }
+        launch_merge<false>(p, x, grid, c.out, c.flags, s);
+        if (need_count) {
+            MECHA_LAUNCH(MK_TIES_FIXUP, ties_amb_collect_kernel, dim3(64), dim3(MECHA_BLOCK), 0, s, p);
+            MECHA_LAUNCH(MK_TIES_FIXUP, ties_amb_select_kernel, dim3((unsigned)n_sd), dim3(MECHA_BLOCK), 0, s, p, c.thresholds_out);
+            MECHA_LAUNCH(MK_TIES_FIXUP, ties_fixup_kernel, dim3(256), dim3(MECHA_BLOCK), 0, s, p, x, c.out, c.flags);
+        }
+    }
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;
 }
@@ -533,16 +1056,27 @@ int run_ties(const TiesCall &c) {
 extern "C" {
 
 size_t mecha_ties_workspace_bytes(int n_models, int64_t numel) {
-    (void)numel;
     if (n_models < 1) n_models = 1;
-    return layout(n_models, 1).total;
+    return layout(n_models, 1, numel).total;
 }
 
 size_t mecha_batched_ties_workspace_bytes(int n_models, int n_segments, int64_t total_elems) {
-    (void)total_elems;
     if (n_models < 1) n_models = 1;
     if (n_segments < 1) n_segments = 1;
-    return layout(n_models, n_segments).total;
+    return layout(n_models, n_segments, total_elems).total;
+}
+
+int mecha_ties_select_stats(const void *workspace, int n_models, int n_segments, int64_t total_elems,
+                            unsigned long long *failed_pairs, unsigned long long *ambiguous_elems, void *stream) {
+    MECHA_REQUIRE(workspace != nullptr && failed_pairs != nullptr && ambiguous_elems != nullptr, "NULL argument");
+    const WorkspaceLayout w = layout(n_models < 1 ? 1 : n_models, n_segments < 1 ? 1 : n_segments, total_elems);
+    TiesGlobals g{};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MECHA_CHECK_HIP(hipMemcpyAsync(&g, static_cast<const char *>(workspace) + w.globals_off, sizeof(g), hipMemcpyDeviceToHost, s));
+    MECHA_CHECK_HIP(hipStreamSynchronize(s));
+    *failed_pairs = g.n_failed;
+    *ambiguous_elems = g.n_amb;
+    return MECHA_OK;
 }
 
 int mecha_ties_sum(const void *const *deltas, int n_models, void *out, int64_t numel, int in_dtype, int out_dtype, double k,
@@ -582,14 +1116,13 @@ int mecha_batched_add_difference_ties(const void *base_arena, const void *const 
                                       int64_t total_elems, int in_dtype, int out_dtype, double k, float alpha, int vote_sgn,
                                       float *thresholds_out, void *workspace, size_t workspace_bytes, uint32_t *seg_flags,
                                       void *stream) {
-    (void)total_elems;
     MECHA_REQUIRE(base_arena != nullptr, "base arena is NULL");
     MECHA_REQUIRE(segments != nullptr, "device segment table is NULL");
     TiesCall c{};
     c.base = base_arena; c.inputs = model_arenas; c.n_deltas = n_models; c.out = out_arena; c.segs_dev = segments;
-    c.segs_host = segments_host; c.n_segs = n_segments; c.in_dt = in_dtype; c.out_dt = out_dtype; c.k = k; c.alpha = alpha;
-    c.vote_sgn = vote_sgn; c.thresholds_out = thresholds_out; c.workspace = workspace; c.workspace_bytes = workspace_bytes;
-    c.flags = seg_flags; c.stream = stream;
+    c.segs_host = segments_host; c.n_segs = n_segments; c.total_elems = total_elems; c.in_dt = in_dtype; c.out_dt = out_dtype;
+    c.k = k; c.alpha = alpha; c.vote_sgn = vote_sgn; c.thresholds_out = thresholds_out; c.workspace = workspace;
+    c.workspace_bytes = workspace_bytes; c.flags = seg_flags; c.stream = stream;
     return run_ties(c);
 }
 

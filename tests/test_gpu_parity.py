@@ -224,6 +224,45 @@ def test_ties_vs_oracle(amd, oracle, n_models, k):
         assert np.array_equal(host_bits(got2), want.view(np.uint32)), (n, "ties_sum fp32 output")
 
 
+@pytest.mark.parametrize("select", ["radix", "fail"])
+def test_ties_selection_fallbacks(amd, oracle, monkeypatch, select):
+    """The threshold selection has two pipelines (ties.hip header).  MECHA_TIES_SELECT=radix runs the radix select alone;
+    =fail makes every bracket of the default pipeline miss, so each (key, delta) pair goes through the in-stream
+    fallback.  Both must give the thresholds and outputs of the default path, i.e. the oracle's."""
+    monkeypatch.setenv("MECHA_TIES_SELECT", select)
+    rng = np.random.default_rng(77)
+    for n, n_models, k in [(4099, 3, 0.2), (300_001, 3, 0.2), ((1 << 20) + 3, 5, 0.35)]:
+        base_b = oracle.from_f32(rng.normal(0, 0.02, size=n).astype(np.float32), "bfloat16")
+        models_b = [oracle.from_f32(rng.normal(0, 0.02, size=n).astype(np.float32), "bfloat16") for _ in range(n_models)]
+        base, models = oracle.to_f32(base_b, "bfloat16"), [oracle.to_f32(m, "bfloat16") for m in models_b]
+        want, det = oracle.ties_sum([oracle.subtract(m, base) for m in models], k=k, details=True)
+        got, thr = amd.add_difference_ties(dev(base_b, "bfloat16"), *[dev(m, "bfloat16") for m in models_b], k=k, alpha=1.0,
+                                           out_dtype=torch.bfloat16, return_thresholds=True)
+        assert np.array_equal(host_bits(thr), det["thresholds"].view(np.uint32)), (select, n)
+        assert np.array_equal(host_bits(got), oracle.from_f32(oracle.add_difference(base, want, 1.0), "bfloat16")), (select, n)
+
+
+@pytest.mark.parametrize("levels", [3, 40, 5000])
+def test_ties_heavy_ties_and_skewed_keys(amd, oracle, levels):
+    """Deltas drawn from a few distinct magnitudes (heavy ties inside one histogram bin -> the bracket's list would
+    overflow -> per-pair fallback), sorted keys (the stratified sample sees a ramp) and keys whose large values sit in
+    one corner (the sample misses them)."""
+    rng = np.random.default_rng(levels)
+    n = 700_003
+    grid = (rng.normal(0, 0.02, size=levels)).astype(np.float32)
+    cases = {
+        "quantised": [grid[rng.integers(0, levels, size=n)] for _ in range(3)],
+        "sorted": [np.sort(rng.normal(0, 0.02, size=n).astype(np.float32)) for _ in range(2)],
+        "corner": [np.concatenate([rng.normal(0, 1e-4, size=n - 5000), rng.normal(0, 1.0, size=5000)]).astype(np.float32) for _ in range(2)],
+    }
+    for name, deltas in cases.items():
+        for k in (0.2, 0.006):
+            want, det = oracle.ties_sum(deltas, k=k, details=True)
+            got, thr = amd.ties_sum(*[dev(d, "float32") for d in deltas], k=k, return_thresholds=True)
+            assert np.array_equal(host_bits(thr), det["thresholds"].view(np.uint32)), (name, k, "thresholds")
+            assert np.array_equal(host_bits(got), want.view(np.uint32)), (name, k, "output")
+
+
 def test_reductions_vs_oracle(amd, oracle):
     rng = np.random.default_rng(9)
     for n in [2, 9, 4097, (1 << 20) + 7]:
