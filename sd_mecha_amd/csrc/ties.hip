@@ -114,6 +114,9 @@ __device__ __forceinline__ void cursor_seek(const TiesParams &p, long long t, Ti
 
 // 8 consecutive elements as fp32, dtype chosen at run time (wave-uniform).
 __device__ __forceinline__ void load_rt(int dt, bool vec, const void *ptr, int64_t e, int valid, float (&v)[8]) {
+#ifdef TIES_EXPERIMENT_STATIC_BF16
+    dt = MECHA_BF16; vec = true;
+#endif
     if (vec) {
         if (dt == MECHA_BF16) load8<MECHA_BF16, true>(ptr, e, v);      // streamed: far larger than any cache between passes
         else if (dt == MECHA_F16) load8<MECHA_F16, true>(ptr, e, v);
@@ -127,6 +130,47 @@ __device__ __forceinline__ void load_rt(int dt, bool vec, const void *ptr, int64
         }
     }
 }
+// The same in two steps for the two hot kernels (count, merge): all the loads of a vector position are issued back to back
+// as raw words, and each input is converted when it is consumed.  W32: 32-bit storage (two 16-byte words per lane).
+template <bool W32> struct Raw8 { u32x4 w[W32 ? 2 : 1]; };
+template <bool W32>
+__device__ __forceinline__ Raw8<W32> load_raw(bool vec, const void *ptr, int64_t e, int valid) {
+    Raw8<W32> r;
+    if (vec) {
+        if constexpr (W32) {
+            const u32x4 *q = reinterpret_cast<const u32x4 *>(reinterpret_cast<const float *>(ptr) + e);
+            r.w[0] = __builtin_nontemporal_load(q);
+            r.w[1] = __builtin_nontemporal_load(q + 1);
+        } else {
+            r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(ptr) + e));
+        }
+    } else {
+        uint32_t t[W32 ? 8 : 4];
+#pragma unroll
+        for (int j = 0; j < (W32 ? 8 : 4); j++) t[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < valid) {
+                if constexpr (W32) t[j] = reinterpret_cast<const uint32_t *>(ptr)[e + j];
+                else t[j >> 1] |= (uint32_t)reinterpret_cast<const uint16_t *>(ptr)[e + j] << (16 * (j & 1));
+            }
+        }
+        r.w[0] = u32x4{t[0], t[1], t[2], t[3]};
+        if constexpr (W32) r.w[1] = u32x4{t[4], t[5], t[6], t[7]};
+    }
+    return r;
+}
+template <bool W32>
+__device__ __forceinline__ void unpack_raw(int dt, const Raw8<W32> &r, float (&v)[8]) {
+    if constexpr (W32) {
+        v[0] = __uint_as_float(r.w[0].x); v[1] = __uint_as_float(r.w[0].y); v[2] = __uint_as_float(r.w[0].z); v[3] = __uint_as_float(r.w[0].w);
+        v[4] = __uint_as_float(r.w[1].x); v[5] = __uint_as_float(r.w[1].y); v[6] = __uint_as_float(r.w[1].z); v[7] = __uint_as_float(r.w[1].w);
+    } else {
+        if (dt == MECHA_BF16) unpack16<MECHA_BF16>(r.w[0], v);
+        else unpack16<MECHA_F16>(r.w[0], v);
+    }
+}
+
 __device__ __forceinline__ float load1_rt(int dt, const void *ptr, int64_t e) {
     return (dt == MECHA_BF16) ? load1<MECHA_BF16>(ptr, e) : (dt == MECHA_F16) ? load1<MECHA_F16>(ptr, e) : load1<MECHA_F32>(ptr, e);
 }
@@ -136,6 +180,9 @@ __device__ __forceinline__ void store1_rt(int dt, void *ptr, int64_t e, float v)
     else store1<MECHA_F32>(ptr, e, v);
 }
 __device__ __forceinline__ void store_rt(int dt, bool vec, void *ptr, int64_t e, int valid, const float (&v)[8]) {
+#ifdef TIES_EXPERIMENT_STATIC_BF16
+    dt = MECHA_BF16; vec = true;
+#endif
     if (vec) {
         if (dt == MECHA_BF16) store8<MECHA_BF16, true>(ptr, e, v);
         else if (dt == MECHA_F16) store8<MECHA_F16, true>(ptr, e, v);
@@ -229,6 +276,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, 
             // bins over lo <= bits <= hi, see bracket_bin(): 1024 cells of 2^shift patterns, two bins per cell
             const uint32_t span = st.hi - st.lo;
             st.shift = (span >= 1024u) ? (uint32_t)(32 - __clz((int)span)) - 10u : 0u;      // span < 2^(shift + 10)
+            st.lo = (st.lo >> st.shift) << st.shift;                      // cells start at lo
             const unsigned long long top = ((((unsigned long long)(st.lo >> st.shift)) + 1024ull) << st.shift) - 1ull;
             if (top < st.hi) st.hi = (uint32_t)top;                       // trims less than one cell off the bracket
         }
@@ -245,27 +293,27 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, 
 // of a coarse power of two, so nearly all the mass (and the kth value) sits on patterns with many trailing zero bits:
 // those get a bin of their own, which is an exact threshold however many elements tie there, while the odd bins
 // collect only the sparse remainder, few enough for the ambiguous list.
-__device__ __forceinline__ uint32_t bracket_bin(uint32_t bits, uint32_t lo, uint32_t shift) {
-    const uint32_t q = (bits >> shift) - (lo >> shift);
-    return 2u * q + ((bits & ((1u << shift) - 1u)) != 0u ? 1u : 0u);
+// `t` = bits - lo, with lo a multiple of 2^shift (ties_sample_kernel aligns it).
+__device__ __forceinline__ uint32_t bracket_bin(uint32_t t, uint32_t shift, uint32_t low_mask) {
+    return ((t + low_mask) >> shift) + (t >> shift);              // ceil(t / 2^shift) + floor(t / 2^shift) = 2q + (remainder != 0)
 }
 
-template <int CAP>
+template <int CAP, bool W32>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, int d0, int nd) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * TIES_BINS words, then 2 * CAP counters
     uint32_t *lds_cnt = lds_hist + nd * TIES_BINS;
+    const uint32_t dump = nd * TIES_BINS + 2 * CAP + (threadIdx.x & 63);   // 64 write-only words after the counters
     for (int i = threadIdx.x; i < nd * TIES_BINS + 2 * CAP; i += MECHA_BLOCK) lds_hist[i] = 0;
     __syncthreads();
     const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
     const long long t0 = (long long)blockIdx.x * chunk;
     const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
     TileCursor cur;
-    uint32_t lo[CAP], shift[CAP];
-    float lo_f[CAP], hi_f[CAP];
+    uint32_t lo[CAP], width[CAP], shift[CAP], low_mask[CAP];
     uint32_t below[CAP];                           // per wave (uniform): elements with |delta| < lo
     bool active[CAP];
 #pragma unroll
-    for (int d = 0; d < CAP; d++) { below[d] = 0; active[d] = false; lo[d] = shift[d] = 0; lo_f[d] = hi_f[d] = 0.0f; }
+    for (int d = 0; d < CAP; d++) { below[d] = 0; active[d] = false; lo[d] = width[d] = shift[d] = low_mask[d] = 0; }
 
     auto flush = [&](int s) {
 #pragma unroll
@@ -303,8 +351,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, i
                 if (d < nd) {
                     const SelectState &st = p.state[(int64_t)cur.s * p.n_deltas + d0 + d];
                     active[d] = st.mode == MODE_PENDING;
-                    lo[d] = st.lo; shift[d] = st.shift;
-                    lo_f[d] = __uint_as_float(st.lo); hi_f[d] = __uint_as_float(st.hi);     // hi <= +inf: ordered compares
+                    lo[d] = st.lo; width[d] = st.hi - st.lo; shift[d] = st.shift; low_mask[d] = (1u << st.shift) - 1u;
                 }
             }
         }
@@ -320,25 +367,36 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, i
             const int valid = (seg.numel - local >= 8) ? 8 : (int)(seg.numel - local);
             const bool vec = p.vec_ok && valid == 8;
             const int64_t e = seg.offset + local;
-            float b[8];
-            if (p.base != nullptr) load_rt(p.in_dt, vec, p.base, e, valid, b);
-            float v[CAP][8];
+            // every load of this position first (pairs the sample already solved are loaded too: they are rare)
+            Raw8<W32> rb, rv[CAP];
+            if (p.base != nullptr) rb = load_raw<W32>(vec, p.base, e, valid);
 #pragma unroll
             for (int d = 0; d < CAP; d++)
-                if (d < nd && active[d]) load_rt(p.in_dt, vec, p.in[d0 + d], e, valid, v[d]);
+                if (d < nd) rv[d] = load_raw<W32>(vec, p.in[d0 + d], e, valid);
+            float b[8];
+            if (p.base != nullptr) unpack_raw<W32>(p.in_dt, rb, b);
+            const bool ragged = __ballot(valid < 8) != 0ull;               // wave-uniform: some lane is at the end of the key
 #pragma unroll
             for (int d = 0; d < CAP; d++) {
                 if (d < nd && active[d]) {
+                    float v[8];
+                    unpack_raw<W32>(p.in_dt, rv[d], v);
+                    if (p.base != nullptr) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];                     // subtract (linear.py:101)
+                    }
+                    if (ragged) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (j >= valid) v[j] = __uint_as_float(0x7fffffffu);              // past the key: above every bracket
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        float x = (p.base != nullptr) ? v[d][j] - b[j] : v[d][j];           // subtract (linear.py:101)
-                        if (valid < 8 && j >= valid) x = __uint_as_float(0x7fffffffu);        // past the key: neither below nor inside
-                        // positive floats order like their bit patterns; NaN compares false twice = above the bracket
-                        const bool is_below = __builtin_fabsf(x) < lo_f[d];
-                        const bool le_hi = __builtin_fabsf(x) <= hi_f[d];
-                        below[d] += (uint32_t)__popcll(__ballot(is_below));
-                        if (le_hi && !is_below)
-                            atomicAdd(&lds_hist[d * TIES_BINS + bracket_bin(__float_as_uint(x) & 0x7fffffffu, lo[d], shift[d])], 1u);
+                        const uint32_t tt = (__float_as_uint(v[j]) & 0x7fffffffu) - lo[d];     // |delta| pattern relative to lo
+                        below[d] += (uint32_t)__popcll(__ballot((int)tt < 0));
+                        // branch-free: values outside the bracket (92% of them) add to a per-lane dump word instead
+                        const uint32_t bin = d * TIES_BINS + bracket_bin(tt, shift[d], low_mask[d]);
+                        atomicAdd(&lds_hist[tt <= width[d] ? bin : dump], 1u);
                     }
                 }
             }
@@ -613,7 +671,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_collect_kernel(TiesParam
     }
 }
 
-template <int CAP, bool DARE>
+template <int CAP, bool DARE, bool W32>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
     const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
     const long long t0 = (long long)blockIdx.x * chunk;
@@ -648,8 +706,16 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             float b[8];
             float poison = 0.0f;                   // fma(x, 0, poison): stays 0 while every input is finite, NaN after inf / NaN
             bool hit = false;                      // some |delta| of this lane lies in an ambiguous bin
+            // every load of this position is issued before the first one is consumed
+            Raw8<W32> rb, rv[CAP];
+            if (p.base != nullptr) rb = load_raw<W32>(vec, p.base, e, valid);
+            if (in_regs) {
+#pragma unroll
+                for (int d = 0; d < CAP; d++)
+                    if (d < p.n_deltas) rv[d] = load_raw<W32>(vec, p.in[d], e, valid);
+            }
             if (p.base != nullptr) {
-                load_rt(p.in_dt, vec, p.base, e, valid, b);
+                unpack_raw<W32>(p.in_dt, rb, b);
 #pragma unroll
                 for (int j = 0; j < 8; j++) poison = __builtin_fmaf(b[j], 0.0f, poison);
             }
@@ -663,13 +729,12 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
                     for (int j = 0; j < 8; j++) f[j] = f[j] - b[j];
                 }
                 if constexpr (DARE) apply_keep_bits(p, m, local, f);
+                if (amb_hi_m >= 0.0f) {            // wave-uniform and rare: this pair's threshold is still provisional
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float mag = __builtin_fabsf(f[j]);
-                    const bool keep = mag >= t_m;
-                    hit |= keep && (mag <= amb_hi_m);
-                    f[j] = keep ? f[j] : 0.0f;
+                    for (int j = 0; j < 8; j++) hit |= (__builtin_fabsf(f[j]) >= t_m) && (__builtin_fabsf(f[j]) <= amb_hi_m);
                 }
+#pragma unroll
+                for (int j = 0; j < 8; j++) f[j] = (__builtin_fabsf(f[j]) >= t_m) ? f[j] : 0.0f;
             };
             float vote[8], acc[8];                 // vote: an fp32 sum (vote_sgn) or an integer count kept in the same registers
             int cnt[8];
@@ -678,12 +743,15 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             float f[CAP][8];
             // sweep 1: the vote  (ties.py:120: sum of signs, or of deltas if vote_sgn), index order from +0
             for (int g = 0; g < p.n_deltas; g += CAP) {
+                if (!in_regs) {
 #pragma unroll
-                for (int d = 0; d < CAP; d++)
-                    if (g + d < p.n_deltas) load_rt(p.in_dt, vec, p.in[g + d], e, valid, f[d]);
+                    for (int d = 0; d < CAP; d++)
+                        if (g + d < p.n_deltas) rv[d] = load_raw<W32>(vec, p.in[g + d], e, valid);
+                }
 #pragma unroll
                 for (int d = 0; d < CAP; d++)
                     if (g + d < p.n_deltas) {
+                        unpack_raw<W32>(p.in_dt, rv[d], f[d]);
                         if (in_regs) filter(g + d, thr[d], amb_hi[d], f[d]);
                         else filter(g + d, prov_threshold(st[g + d]), (st[g + d].mode == MODE_AMBIG) ? __uint_as_float(st[g + d].amb_hi) : -1.0f, f[d]);
                         if (x.vote_sgn) {
@@ -713,8 +781,11 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
                 if (!in_regs) {
 #pragma unroll
                     for (int d = 0; d < CAP; d++)
+                        if (g + d < p.n_deltas) rv[d] = load_raw<W32>(vec, p.in[g + d], e, valid);
+#pragma unroll
+                    for (int d = 0; d < CAP; d++)
                         if (g + d < p.n_deltas) {
-                            load_rt(p.in_dt, vec, p.in[g + d], e, valid, f[d]);
+                            unpack_raw<W32>(p.in_dt, rv[d], f[d]);
                             filter(g + d, prov_threshold(st[g + d]), -1.0f, f[d]);
                         }
                 }
@@ -736,7 +807,9 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             for (int j = 0; j < 8; j++) {
                 float q = (acc[j] * fs[j]) / (float)cnt[j];
                 if (nonfinite_f32(q)) q = 0.0f;                                     // nan_to_num(nan=0, posinf=0, neginf=0)
-                if (x.has_rescale) q = q / x.rescale_div;                           // ties.py:50
+                if constexpr (DARE) {
+                    if (x.has_rescale) q = q / x.rescale_div;                       // ties.py:50
+                }
                 if (p.base != nullptr) q = __builtin_fmaf(q, x.alpha, b[j]);        // base.addcmul(ties, alpha)  (linear.py:76)
                 r[j] = q;
                 bad_out |= (j < valid) && nonfinite_f32(q);
@@ -911,11 +984,18 @@ void launch_hist(const TiesParams &p, unsigned grid, hipStream_t s) {
 }
 
 void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
-    for (int d0 = 0; d0 < p.n_deltas; d0 += TIES_GROUP) {
-        const int nd = (p.n_deltas - d0 < TIES_GROUP) ? p.n_deltas - d0 : TIES_GROUP;
-        if (nd <= 2) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<2>), dim3(grid), dim3(MECHA_BLOCK), ((size_t)nd * TIES_BINS + 4) * sizeof(uint32_t), s, p, d0, nd);
-        else if (nd <= 4) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<4>), dim3(grid), dim3(MECHA_BLOCK), ((size_t)nd * TIES_BINS + 8) * sizeof(uint32_t), s, p, d0, nd);
-        else MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<8>), dim3(grid), dim3(MECHA_BLOCK), ((size_t)nd * TIES_BINS + 16) * sizeof(uint32_t), s, p, d0, nd);
+    constexpr int COUNT_GROUP = 7;                 // 7 histograms + counters + dump words stay inside 64 KiB of LDS
+    for (int d0 = 0; d0 < p.n_deltas; d0 += COUNT_GROUP) {
+        const int nd = (p.n_deltas - d0 < COUNT_GROUP) ? p.n_deltas - d0 : COUNT_GROUP;
+        // LDS: nd histograms, 2 * CAP counters, 64 dump words
+        const int cap = nd <= 2 ? 2 : (nd <= 4 ? 4 : 8);
+        const size_t lds = ((size_t)nd * TIES_BINS + 2 * cap + 64) * sizeof(uint32_t);
+        const bool w32 = p.in_dt == MECHA_F32;
+#define MECHA_COUNT_LAUNCH(CAP_, W32_) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd)
+        if (cap == 2) { if (w32) MECHA_COUNT_LAUNCH(2, true); else MECHA_COUNT_LAUNCH(2, false); }
+        else if (cap == 4) { if (w32) MECHA_COUNT_LAUNCH(4, true); else MECHA_COUNT_LAUNCH(4, false); }
+        else { if (w32) MECHA_COUNT_LAUNCH(8, true); else MECHA_COUNT_LAUNCH(8, false); }
+#undef MECHA_COUNT_LAUNCH
     }
 }
 
@@ -932,9 +1012,12 @@ void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float 
 
 template <bool DARE>
 void launch_merge(const TiesParams &p, const MergeExtra &x, unsigned grid, void *out, uint32_t *flags, hipStream_t s) {
-    if (p.n_deltas <= 2) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<2, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
-    else if (p.n_deltas <= 4) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<4, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
-    else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<8, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    const bool w32 = p.in_dt == MECHA_F32;
+#define MECHA_MERGE_LAUNCH(CAP_, W32_) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<CAP_, DARE, W32_>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags)
+    if (p.n_deltas <= 2) { if (w32) MECHA_MERGE_LAUNCH(2, true); else MECHA_MERGE_LAUNCH(2, false); }
+    else if (p.n_deltas <= 4) { if (w32) MECHA_MERGE_LAUNCH(4, true); else MECHA_MERGE_LAUNCH(4, false); }
+    else { if (w32) MECHA_MERGE_LAUNCH(8, true); else MECHA_MERGE_LAUNCH(8, false); }
+#undef MECHA_MERGE_LAUNCH
 }
 
 int run_ties(const TiesCall &c) {
