@@ -65,6 +65,7 @@ constexpr int MECHA_VEC = 8;                       // elements per lane per vect
 // ---------------------------------------------------------------- conversions
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t h) {

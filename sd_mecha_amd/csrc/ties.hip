@@ -704,7 +704,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             const bool vec = p.vec_ok && valid == 8;
             const int64_t e = seg.offset + local;
             float b[8];
-            float poison = 0.0f;                   // fma(x, 0, poison): stays 0 while every input is finite, NaN after inf / NaN
+            f32x2 poison = {0.0f, 0.0f};           // fma(x, 0, poison): stays 0 while every input is finite, NaN after inf / NaN (v_pk_fma_f32)
             bool hit = false;                      // some |delta| of this lane lies in an ambiguous bin
             // every load of this position is issued before the first one is consumed
             Raw8<W32> rb, rv[CAP];
@@ -717,13 +717,13 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             if (p.base != nullptr) {
                 unpack_raw<W32>(p.in_dt, rb, b);
 #pragma unroll
-                for (int j = 0; j < 8; j++) poison = __builtin_fmaf(b[j], 0.0f, poison);
+                for (int j = 0; j < 8; j += 2) poison = __builtin_elementwise_fma(f32x2{b[j], b[j + 1]}, f32x2{0.0f, 0.0f}, poison);
             }
             // filtered delta f_m = delta_m * (|delta_m| >= thr_m)   (ties.py:128-132); a select gives the same values
             // up to the sign of a zero, which neither the vote (sign(+-0) = 0) nor the sums (from +0) can see
             auto filter = [&](int m, float t_m, float amb_hi_m, float (&f)[8]) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) poison = __builtin_fmaf(f[j], 0.0f, poison);
+                for (int j = 0; j < 8; j += 2) poison = __builtin_elementwise_fma(f32x2{f[j], f[j + 1]}, f32x2{0.0f, 0.0f}, poison);
                 if (p.base != nullptr) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) f[j] = f[j] - b[j];
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
 #pragma unroll
                             for (int j = 0; j < 8; j++) {
                                 const int sb = (int)__float_as_uint(f[d][j] + 0.0f);
-                                vote[j] = __int_as_float(__float_as_int(vote[j]) + (sb > 1 ? 1 : (sb < -1 ? -1 : sb)));
+                                vote[j] = __int_as_float(__float_as_int(vote[j]) + __builtin_elementwise_min(__builtin_elementwise_max(sb, -1), 1));   // v_med3_i32
                             }
                         }
                     }
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int vi = __float_as_int(vote[j]);
-                fs[j] = x.vote_sgn ? sign_f(vote[j]) : (float)((vi > 0) - (vi < 0));
+                fs[j] = x.vote_sgn ? sign_f(vote[j]) : (float)__builtin_elementwise_min(__builtin_elementwise_max(vi, -1), 1);
             }
             // sweep 2: disjoint mean over the deltas whose sign agrees (ties.py:122-124, :110).  g = f * fs is positive
             // exactly for the agreeing non-zero deltas; summing |f| = g and restoring the sign afterwards rounds like
@@ -794,26 +794,29 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
                     if (g + d < p.n_deltas) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            const float gj = f[d][j] * fs[j];
-                            acc[j] += __builtin_fmaxf(gj, 0.0f);
-                            cnt[j] += gj > 0.0f;
+                            const float gj = __builtin_fmaxf(f[d][j] * fs[j], 0.0f);
+                            acc[j] += gj;
+                            // gj is +-0 or positive: 1 iff gj > 0, from the bit pattern (v_med3_i32; -0 clamps to 0)
+                            cnt[j] += __builtin_elementwise_min(__builtin_elementwise_max(__float_as_int(gj), 0), 1);
                         }
                     }
             }
-            const bool bad_in = poison != poison;
+            const bool bad_in = (poison.x != poison.x) | (poison.y != poison.y);
             float r[8];
-            bool bad_out = false;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 float q = (acc[j] * fs[j]) / (float)cnt[j];
-                if (nonfinite_f32(q)) q = 0.0f;                                     // nan_to_num(nan=0, posinf=0, neginf=0)
+                q = __builtin_amdgcn_class(q, 0x1f8) ? q : 0.0f;                    // nan_to_num(nan=0, posinf=0, neginf=0): keep finite classes
                 if constexpr (DARE) {
                     if (x.has_rescale) q = q / x.rescale_div;                       // ties.py:50
                 }
                 if (p.base != nullptr) q = __builtin_fmaf(q, x.alpha, b[j]);        // base.addcmul(ties, alpha)  (linear.py:76)
                 r[j] = q;
-                bad_out |= (j < valid) && nonfinite_f32(q);
             }
+            f32x2 out_poison = {0.0f, 0.0f};       // lanes past the end of a key hold zeros: they cannot raise it
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) out_poison = __builtin_elementwise_fma(f32x2{r[j], r[j + 1]}, f32x2{0.0f, 0.0f}, out_poison);
+            const bool bad_out = (out_poison.x != out_poison.x) | (out_poison.y != out_poison.y);
             store_rt(p.out_dt, vec, out, e, valid, r);
             if ((bad_in | bad_out) && flags != nullptr)
                 atomicOr(flags + (p.tile_start == nullptr ? 0 : cur.s),
