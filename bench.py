@@ -16,6 +16,7 @@ import argparse
 import ctypes
 import json
 import os
+import pathlib
 import sys
 import time
 
@@ -200,6 +201,12 @@ def main():
         dom = max((k for k in kernels if k in per_launch_bytes), key=lambda k: kernels[k][0])
         dom_ms = kernels[dom][0] / kernels[dom][1]
         achieved = per_launch_bytes[dom] / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters: they need rocprofv3, so they are collected in separate runs of this
+        # same command and committed under profiles/ (how: the file's "_how"); None when this workload was not measured
+        traffic = None
+        traffic_file = pathlib.Path(__file__).resolve().parent / "profiles" / "r01_hbm_traffic.json"
+        if traffic_file.exists():
+            traffic = json.loads(traffic_file.read_text()).get(args.workload, {}).get(dom, {}).get("hbm_bytes_per_launch")
         line = {
             "metric": "merged state-dict GB/s", "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True,
@@ -209,7 +216,7 @@ def main():
                        "storage_dtype": "bf16 in / bf16 out", "parallelism": f"key stripes x{world}, no collective"},
             "hbm_frac_whole_step": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes[dom], "avg_launch_ms": round(dom_ms, 4)},
             "kernels": breakdown,
         }

@@ -740,7 +740,10 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             int cnt[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) { vote[j] = 0.0f; acc[j] = 0.0f; cnt[j] = 0; }
-            float f[CAP][8];
+            // up to 4 deltas: the filtered deltas stay in registers between the sweeps; beyond, sweep 2 converts and filters
+            // the raw words again (4 VGPRs per delta instead of 8 keeps the 8-delta kernel at a usable occupancy)
+            constexpr bool KEEP_F = CAP <= 4;
+            float f[KEEP_F ? CAP : 1][8];
             // sweep 1: the vote  (ties.py:120: sum of signs, or of deltas if vote_sgn), index order from +0
             for (int g = 0; g < p.n_deltas; g += CAP) {
                 if (!in_regs) {
@@ -751,17 +754,18 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
 #pragma unroll
                 for (int d = 0; d < CAP; d++)
                     if (g + d < p.n_deltas) {
-                        unpack_raw<W32>(p.in_dt, rv[d], f[d]);
-                        if (in_regs) filter(g + d, thr[d], amb_hi[d], f[d]);
-                        else filter(g + d, prov_threshold(st[g + d]), (st[g + d].mode == MODE_AMBIG) ? __uint_as_float(st[g + d].amb_hi) : -1.0f, f[d]);
+                        float (&fd)[8] = f[KEEP_F ? d : 0];
+                        unpack_raw<W32>(p.in_dt, rv[d], fd);
+                        if (in_regs) filter(g + d, thr[d], amb_hi[d], fd);
+                        else filter(g + d, prov_threshold(st[g + d]), (st[g + d].mode == MODE_AMBIG) ? __uint_as_float(st[g + d].amb_hi) : -1.0f, fd);
                         if (x.vote_sgn) {
 #pragma unroll
-                            for (int j = 0; j < 8; j++) vote[j] += f[d][j];
+                            for (int j = 0; j < 8; j++) vote[j] += fd[j];
                         } else {
                             // sign(f) as an integer: clamp the bit pattern of f + 0 (the add turns -0 into +0) to [-1, 1]
 #pragma unroll
                             for (int j = 0; j < 8; j++) {
-                                const int sb = (int)__float_as_uint(f[d][j] + 0.0f);
+                                const int sb = (int)__float_as_uint(fd[j] + 0.0f);
                                 vote[j] = __int_as_float(__float_as_int(vote[j]) + __builtin_elementwise_min(__builtin_elementwise_max(sb, -1), 1));   // v_med3_i32
                             }
                         }
@@ -782,19 +786,18 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
 #pragma unroll
                     for (int d = 0; d < CAP; d++)
                         if (g + d < p.n_deltas) rv[d] = load_raw<W32>(vec, p.in[g + d], e, valid);
-#pragma unroll
-                    for (int d = 0; d < CAP; d++)
-                        if (g + d < p.n_deltas) {
-                            unpack_raw<W32>(p.in_dt, rv[d], f[d]);
-                            filter(g + d, prov_threshold(st[g + d]), -1.0f, f[d]);
-                        }
                 }
 #pragma unroll
                 for (int d = 0; d < CAP; d++)
                     if (g + d < p.n_deltas) {
+                        float (&fd)[8] = f[KEEP_F ? d : 0];
+                        if (!KEEP_F || !in_regs) {         // the filtered delta again, from the raw words
+                            unpack_raw<W32>(p.in_dt, rv[d], fd);
+                            filter(g + d, in_regs ? thr[d] : prov_threshold(st[g + d]), -1.0f, fd);
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            const float gj = __builtin_fmaxf(f[d][j] * fs[j], 0.0f);
+                            const float gj = __builtin_fmaxf(fd[j] * fs[j], 0.0f);
                             acc[j] += gj;
                             // gj is +-0 or positive: 1 iff gj > 0, from the bit pattern (v_med3_i32; -0 clamps to 0)
                             cnt[j] += __builtin_elementwise_min(__builtin_elementwise_max(__float_as_int(gj), 0), 1);
