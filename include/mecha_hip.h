@@ -226,6 +226,24 @@ int mecha_batched_add_difference_ties(const void *base_arena, const void *const 
                                       float alpha, int vote_sgn, float *thresholds_out, void *workspace,
                                       size_t workspace_bytes, uint32_t *seg_flags, void *stream);
 
+/* HOST functions: the file traffic of one wave of keys, between safetensors files and pinned
+ * staging arenas, moved by up to `threads` workers in pieces of 4 MiB.
+ * mecha_host_pread_many replaces InSafetensorsDict._load_tensor's locked readinto window + clone
+ * (streaming.py:151-178) for the batched path: entry i reads nbytes[i] bytes at file offset
+ * offsets[i] of fds[i] into dst[i]; fds[i] < 0 zero-fills dst[i] instead (arena gaps).
+ * mecha_host_pwrite_many replaces OutSafetensorsDict's per-thread buffer flushed under one lock
+ * (streaming.py:277-308): entry i writes nbytes[i] bytes from src[i] at file offset offsets[i].
+ * All arrays are host arrays of length n.  Return 0, or < 0 with mecha_last_error() set. */
+int mecha_host_pread_many(const int *fds, void *const *dst, const size_t *nbytes,
+                          const int64_t *offsets, int64_t n, int threads);
+int mecha_host_pwrite_many(int fd, const void *const *src, const size_t *nbytes,
+                           const int64_t *offsets, int64_t n, int threads);
+/* The same list stored through a MAP_SHARED mapping of the file (buffered pwrites to one file
+ * serialise on its inode lock; page faults of a mapping do not).  The file must already be long
+ * enough for the furthest entry. */
+int mecha_host_mmap_write_many(int fd, const void *const *src, const size_t *nbytes,
+                               const int64_t *offsets, int64_t n, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,125 @@
+// hostio.cpp -- host side of the key scheduler's file traffic: many-piece pread / pwrite on a small thread team.
+//
+// Replaces, for the batched path, the reference's per-key `readinto` window + clone (streaming.py:151-178, one lock per
+// file) and its per-thread write buffer flushed under one lock (streaming.py:277-308): the scheduler hands over the whole
+// scatter list of a wave (file offset -> address inside a pinned staging arena, or the reverse) and the pieces are moved
+// by up to `threads` workers straight between the page cache and pinned memory.  No torch, no HIP: plain POSIX.
+#include <errno.h>
+#include <stdint.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr size_t PIECE = (size_t)4 << 20;          // work unit: 4 MiB, so that one 100 MB tensor spreads over the team
+
+struct Piece { int64_t entry; size_t skip, len; };
+
+std::vector<Piece> split(const size_t *nbytes, int64_t n) {
+    std::vector<Piece> pieces;
+    for (int64_t i = 0; i < n; i++)
+        for (size_t done = 0; done < nbytes[i]; done += PIECE)
+            pieces.push_back(Piece{i, done, nbytes[i] - done < PIECE ? nbytes[i] - done : PIECE});
+    return pieces;
+}
+
+template <typename F>
+int run_team(const std::vector<Piece> &pieces, int threads, F &&one) {
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > pieces.size()) threads = (int)(pieces.size() ? pieces.size() : 1);
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= pieces.size() || err.load(std::memory_order_relaxed) != 0) return;
+            const int e = one(pieces[i]);
+            if (e != 0) err.store(e, std::memory_order_relaxed);
+        }
+    };
+    std::vector<std::thread> team;
+    for (int t = 1; t < threads; t++) team.emplace_back(worker);
+    worker();
+    for (auto &t : team) t.join();
+    return err.load();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mecha_host_pread_many(const int *fds, void *const *dst, const size_t *nbytes, const int64_t *offsets, int64_t n, int threads) {
+    MECHA_REQUIRE(n >= 0 && (n == 0 || (fds != nullptr && dst != nullptr && nbytes != nullptr && offsets != nullptr)), "NULL argument");
+    const std::vector<Piece> pieces = split(nbytes, n);
+    const int e = run_team(pieces, threads, [&](const Piece &p) -> int {
+        char *out = static_cast<char *>(dst[p.entry]) + p.skip;
+        if (fds[p.entry] < 0) { memset(out, 0, p.len); return 0; }           // a gap of the arena: keep it finite
+        size_t done = 0;
+        while (done < p.len) {
+            const ssize_t got = pread(fds[p.entry], out + done, p.len - done, (off_t)(offsets[p.entry] + (int64_t)(p.skip + done)));
+            if (got < 0) { if (errno == EINTR) continue; return errno; }
+            if (got == 0) return EIO;                                           // the file is shorter than its header says
+            done += (size_t)got;
+        }
+        return 0;
+    });
+    MECHA_REQUIRE(e == 0, "pread failed: %s", strerror(e));
+    return MECHA_OK;
+}
+
+int mecha_host_pwrite_many(int fd, const void *const *src, const size_t *nbytes, const int64_t *offsets, int64_t n, int threads) {
+    MECHA_REQUIRE(fd >= 0 && n >= 0 && (n == 0 || (src != nullptr && nbytes != nullptr && offsets != nullptr)), "bad argument");
+    const std::vector<Piece> pieces = split(nbytes, n);
+    const int e = run_team(pieces, threads, [&](const Piece &p) -> int {
+        const char *in = static_cast<const char *>(src[p.entry]) + p.skip;
+        size_t done = 0;
+        while (done < p.len) {
+            const ssize_t put = pwrite(fd, in + done, p.len - done, (off_t)(offsets[p.entry] + (int64_t)(p.skip + done)));
+            if (put < 0) { if (errno == EINTR) continue; return errno; }
+            done += (size_t)put;
+        }
+        return 0;
+    });
+    MECHA_REQUIRE(e == 0, "pwrite failed: %s", strerror(e));
+    return MECHA_OK;
+}
+
+// The same scatter list through a shared mapping of the output file.  Buffered pwrite()s to ONE file serialise on its
+// inode lock whatever the number of threads; stores into a MAP_SHARED mapping fault pages in independently, so the team
+// scales.  The file must already be at least as long as the furthest piece (the writer ftruncates it at creation).
+int mecha_host_mmap_write_many(int fd, const void *const *src, const size_t *nbytes, const int64_t *offsets, int64_t n, int threads) {
+    MECHA_REQUIRE(fd >= 0 && n >= 0 && (n == 0 || (src != nullptr && nbytes != nullptr && offsets != nullptr)), "bad argument");
+    int64_t lo = INT64_MAX, hi = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (nbytes[i] == 0) continue;
+        MECHA_REQUIRE(offsets[i] >= 0, "negative file offset");
+        if (offsets[i] < lo) lo = offsets[i];
+        if (offsets[i] + (int64_t)nbytes[i] > hi) hi = offsets[i] + (int64_t)nbytes[i];
+    }
+    if (hi == 0) return MECHA_OK;
+    struct stat st;
+    MECHA_REQUIRE(fstat(fd, &st) == 0, "fstat failed: %s", strerror(errno));
+    MECHA_REQUIRE((int64_t)st.st_size >= hi, "output file holds %lld bytes, the scatter list reaches %lld: ftruncate it first",
+                  (long long)st.st_size, (long long)hi);
+    const int64_t page = sysconf(_SC_PAGESIZE);
+    const int64_t map_lo = lo / page * page;
+    void *base = mmap(nullptr, (size_t)(hi - map_lo), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)map_lo);
+    MECHA_REQUIRE(base != MAP_FAILED, "mmap of the output file failed: %s", strerror(errno));
+    const std::vector<Piece> pieces = split(nbytes, n);
+    run_team(pieces, threads, [&](const Piece &p) -> int {
+        memcpy(static_cast<char *>(base) + (offsets[p.entry] - map_lo) + p.skip, static_cast<const char *>(src[p.entry]) + p.skip, p.len);
+        return 0;
+    });
+    MECHA_REQUIRE(munmap(base, (size_t)(hi - map_lo)) == 0, "munmap failed: %s", strerror(errno));
+    return MECHA_OK;
+}
+
+}  // extern "C"

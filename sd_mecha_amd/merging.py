@@ -20,10 +20,13 @@ check_finite_output (:112-146).
 """
 from __future__ import annotations
 
+import concurrent.futures
 import logging
 import math
+import os
 import pathlib
 import threading
+import time
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Mapping, MutableMapping, Optional, Sequence, Tuple
 
@@ -201,6 +204,21 @@ def _plan_waves(items: Sequence[Tuple[str, int]], wave_elems: int) -> List[_Wave
     return [_Wave([k for k, _ in w], plan_arena(w)) for w in waves]
 
 
+# host seconds per phase of the last fused merge() of this process (tools/bench_e2e.py prints it)
+last_stats: Dict[str, float] = {}
+
+
+class _phase:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *a):
+        last_stats[self.name] = last_stats.get(self.name, 0.0) + time.perf_counter() - self.t0
+
+
 def _dist_info():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -352,30 +370,50 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
             "d_out": torch.empty(cap, dtype=output_dtype, device=dev),
             "flags": None, "h_flags": None, "ev_h2d": None, "ev_comp": None, "ev_d2h": None, "wave": None,
         }
-    sets = [alloc_set(), alloc_set()] if len(waves) > 1 else [alloc_set()]
+    last_stats.clear()
+    with _phase("alloc"):
+        sets = [alloc_set(), alloc_set()] if len(waves) > 1 else [alloc_set()]
     s_copy_in = backend.stream() if is_cuda else None
     s_comp = backend.stream() if is_cuda else None
     s_copy_out = backend.stream() if is_cuda else None
 
-    def stage(bs, wave: _Wave):
-        """mmap -> pinned staging: one memcpy per (model, key) into the arena offsets."""
-        L = wave.layout
-        esz = in_esz
+    host_threads = max(1, min(int(os.environ.get("MECHA_HOST_THREADS", "16")), os.cpu_count() or 1))
+    writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+    hostlib = _lib.lib()
 
-        def fill(mi):
+    def stage(bs, wave: _Wave):
+        """files -> pinned staging: one scatter list per wave (every (model, key) pair to its arena offset, and the
+        gaps after each key zero-filled so they stay finite), moved by the library's host thread team."""
+        L = wave.layout
+        nk = len(L.keys)
+        offs = np.asarray(L.offsets, dtype=np.int64)
+        nums = np.asarray(L.numels, dtype=np.int64)
+        ends = offs + nums
+        gaps = np.minimum((ends + 127) // 128 * 128, cap) - ends
+        has_gap = gaps > 0
+        fds, dsts, sizes, foffs = [], [], [], []
+        for mi in range(n_models):
             reader = readers[id(plan.models[mi])]
-            dst = bs["h_in"][mi].view(torch.uint8).numpy()
-            for key, off, n in zip(L.keys, L.offsets, L.numels):
-                dst[off * esz:(off + n) * esz] = np.frombuffer(reader.raw(key), dtype=np.uint8)
-                pad_end = (off + n + 127) // 128 * 128
-                dst[(off + n) * esz:min(pad_end, cap) * esz] = 0               # gaps stay finite
-        threads = [threading.Thread(target=fill, args=(mi,)) for mi in range(n_models)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+            base = bs["h_in"][mi].data_ptr()
+            fds += [np.full(nk, reader.fileno(), dtype=np.int32), np.full(int(has_gap.sum()), -1, dtype=np.int32)]
+            dsts += [base + offs * in_esz, base + ends[has_gap] * in_esz]
+            sizes += [nums * in_esz, gaps[has_gap] * in_esz]
+            foffs += [np.fromiter((reader.file_offset(k) for k in L.keys), dtype=np.int64, count=nk), np.zeros(int(has_gap.sum()), dtype=np.int64)]
+        fds_a = np.ascontiguousarray(np.concatenate(fds), dtype=np.int32)
+        dst_a = np.ascontiguousarray(np.concatenate(dsts), dtype=np.uint64)
+        size_a = np.ascontiguousarray(np.concatenate(sizes), dtype=np.uint64)
+        foff_a = np.ascontiguousarray(np.concatenate(foffs), dtype=np.int64)
+        _lib.check(hostlib.mecha_host_pread_many(fds_a.ctypes.data, dst_a.ctypes.data, size_a.ctypes.data, foff_a.ctypes.data,
+                                                 len(fds_a), host_threads), "mecha_host_pread_many")
+
+    def wait_write(bs):
+        fut = bs.pop("write_fut", None)
+        if fut is not None:
+            with _phase("wait_write"):
+                fut.result()
 
     def launch(bs, wave: _Wave):
+        wait_write(bs)
         L = wave.layout
         bs["wave"] = wave
         segs_host = L.host_segments()
@@ -417,10 +455,12 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
         if wave is None:
             return
         if is_cuda:
-            bs["ev_d2h"].synchronize()
+            with _phase("drain_wait_gpu"):
+                bs["ev_d2h"].synchronize()
         L = wave.layout
         fl = bs["h_flags"].numpy()
-        out_bytes = bs["h_out"].view(torch.uint8).numpy()
+        out_base = bs["h_out"].data_ptr()
+        put_keys, put_metas, put_ptrs = [], [], []
         for i, (key, off, n) in enumerate(zip(L.keys, L.offsets, L.numels)):
             meta = header[key]
             if fl[i] & _lib.FLAG_INPUT_NONFINITE:
@@ -430,25 +470,43 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
             if (fl[i] & _lib.FLAG_OUTPUT_NONFINITE) and check_finite_output:
                 log.warning("There are non finite values in key '%s': %s", key, meta)     # merging.py:303-308
             if to_file:
-                sink.put(key, meta, out_bytes[off * out_esz:(off + n) * out_esz])
+                put_keys.append(key)
+                put_metas.append(meta)
+                put_ptrs.append(out_base + off * out_esz)
             else:
                 t = bs["h_out"][off:off + n].clone().view(meta.shape)
                 sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t
+        if to_file:
+            # one scatter list per wave, written by the host team behind the scheduler's back: the next wave's staging
+            # and launches overlap the page-cache work of this write; launch() waits before it reuses this set's h_out
+            def write(keys=put_keys, metas=put_metas, ptrs=put_ptrs):
+                with _phase("write"):
+                    sink.put_many(keys, metas, ptrs, host_threads)
+            bs["write_fut"] = writer.submit(write)
         bs["wave"] = None
 
     # software pipeline over waves: stage(w+1) on the host overlaps H2D/compute/D2H of w
-    stage(sets[0], waves[0])
+    with _phase("stage"):
+        stage(sets[0], waves[0])
     for w, wave in enumerate(waves):
         bs = sets[w % len(sets)]
-        launch(bs, wave)
+        with _phase("launch"):
+            launch(bs, wave)
         if w + 1 < len(waves):
             nxt = sets[(w + 1) % len(sets)]
-            drain(nxt)                      # the set we are about to refill must have been written out
-            stage(nxt, waves[w + 1])
+            with _phase("drain"):
+                drain(nxt)                  # the set we are about to refill must have been written out
+            with _phase("stage"):
+                stage(nxt, waves[w + 1])
+    with _phase("drain"):
+        for bs in sets:
+            drain(bs)
     for bs in sets:
-        drain(bs)
+        wait_write(bs)
+    writer.shutdown()
     if is_cuda:
         torch.cuda.synchronize(dev)
+    last_stats["waves"] = len(waves)
 
 
 def _write_fallback(plan, readers, key, meta, sink, to_file, output_device, output_dtype) -> bool:

@@ -24,7 +24,7 @@ import pathlib
 import struct
 import threading
 from collections import OrderedDict
-from typing import Dict, Iterable, Iterator, Mapping, Optional, Tuple
+from typing import Dict, Iterable, Iterator, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -131,6 +131,13 @@ class InSafetensorsDict(Mapping):
         hi = self.data_start + m.end if n_elems is None else lo + n_elems * esz
         return self._view[lo:hi]
 
+    def fileno(self) -> int:
+        return self._file.fileno()
+
+    def file_offset(self, key: str) -> int:
+        """Absolute file offset of a tensor's first byte (for the scheduler's pread scatter lists)."""
+        return self.data_start + self.meta(key).start
+
     def __getitem__(self, key: str) -> torch.Tensor:
         m = self.meta(key)
         if m.end == m.start:
@@ -182,6 +189,21 @@ class OutSafetensorsDict:
         self.data_start = 8 + self.max_header_size
         flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
         self._fd = os.open(self.file_path, flags, 0o644)
+        self._prealloc = None
+        if create:
+            # Full length up front (every key of the header merged): put_many stores through a mapping of the file.
+            # Allocating the pages first (in the background, while the first wave is staged) makes those stores 3x
+            # faster on tmpfs / the page cache than faulting fresh pages in (tools/write_bench.cpp: 12 vs 4.4 GB/s).
+            size = self.data_start + sum(m.nbytes() for m in header.values())
+            os.ftruncate(self._fd, size)
+
+            def prealloc(fd=self._fd):
+                try:
+                    os.posix_fallocate(fd, 0, size)
+                except OSError:
+                    pass                                   # file systems without fallocate: the ftruncate above is enough
+            self._prealloc = threading.Thread(target=prealloc, daemon=True)
+            self._prealloc.start()
         self._lock = threading.Lock()
         self._cursor = region_start                       # next free byte of this writer's region (data-section relative)
         self.entries: Dict[str, dict] = {}
@@ -199,6 +221,26 @@ class OutSafetensorsDict:
             written += os.pwrite(self._fd, view[written:], self.data_start + off + written)
         self.entries[key] = {"dtype": DTYPE_REVERSE_MAPPING[meta.dtype][0], "shape": list(meta.shape), "data_offsets": [off, off + len(view)]}
 
+    def put_many(self, keys: Sequence[str], metas: Sequence[TensorMetadata], src_ptrs, threads: int) -> None:
+        """Append many tensors whose bytes already sit in host memory (a drained staging arena): file offsets are
+        assigned in order under the lock, the bytes go out through libmecha_hip's host thread team."""
+        if not keys:
+            return
+        from . import _lib
+        self._join_prealloc()
+        sizes = np.fromiter((m.nbytes() for m in metas), dtype=np.uint64, count=len(keys))
+        with self._lock:
+            first = self._cursor
+            self._cursor += int(sizes.sum())
+        rel = first + np.concatenate(([0], np.cumsum(sizes[:-1], dtype=np.uint64))).astype(np.int64)
+        srcs = np.ascontiguousarray(src_ptrs, dtype=np.uint64)
+        offs = np.ascontiguousarray(rel + self.data_start, dtype=np.int64)
+        args = (self._fd, srcs.ctypes.data, sizes.ctypes.data, offs.ctypes.data, len(keys), threads)
+        if _lib.lib().mecha_host_mmap_write_many(*args) != 0:               # e.g. a file system without shared mappings
+            _lib.check(_lib.lib().mecha_host_pwrite_many(*args), "mecha_host_pwrite_many")
+        for key, meta, off, n in zip(keys, metas, rel.tolist(), sizes.tolist()):
+            self.entries[key] = {"dtype": DTYPE_REVERSE_MAPPING[meta.dtype][0], "shape": list(meta.shape), "data_offsets": [off, off + n]}
+
     def __setitem__(self, key: str, tensor: torch.Tensor) -> None:
         """WriteOnlyMapping protocol of the reference (typing_.py:12-20): tensor -> bytes -> file."""
         self.put(key, TensorMetadata(tensor.shape, tensor.dtype), tensor_bytes(tensor))
@@ -207,9 +249,15 @@ class OutSafetensorsDict:
     def bytes_written(self) -> int:
         return self._cursor
 
+    def _join_prealloc(self):
+        t, self._prealloc = self._prealloc, None
+        if t is not None:
+            t.join()
+
     def close(self, extra_entries: Optional[Mapping[str, dict]] = None, write_header: bool = True) -> None:
         if self._fd is None:
             return
+        self._join_prealloc()
         if write_header:
             header = OrderedDict()
             header["__metadata__"] = self.metadata
@@ -223,6 +271,8 @@ class OutSafetensorsDict:
                 raise RuntimeError("safetensors header outgrew its reserved space")   # cannot happen: worst case reserved
             os.pwrite(self._fd, struct.pack("<Q", self.max_header_size), 0)
             os.pwrite(self._fd, blob + b" " * (self.max_header_size - len(blob)), 8)
+            # keys the header promised but nobody wrote (skipped at run time) leave slack at the end
+            os.ftruncate(self._fd, self.data_start + max((v["data_offsets"][1] for v in entries.values()), default=0))
         os.close(self._fd)
         self._fd = None
 

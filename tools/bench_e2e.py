@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""End-to-end `merge()` timing: safetensors files on tmpfs -> pinned staging -> H2D -> HIP kernels -> D2H -> one output
+file (SURVEY.md §8d "Merged GB/s, whole node": input bytes + output bytes over the wall time of merge() from the first
+read to close()).  This is the host-link-inclusive number DESIGN.md quotes beside bench.py's HBM-resident `value`.
+
+    python tools/bench_e2e.py --workload sdxl_ties --dir /dev/shm/mecha_e2e
+
+Synthetic checkpoints (N(0, 0.02^2) rounded to bf16, shapes from the exported manifest) are written once into --dir and
+removed afterwards.  Also measures the pinned-memory hipMemcpyAsync rate of this box, the roofline of the host link."""
+import argparse
+import json
+import os
+import pathlib
+import shutil
+import sys
+import time
+
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import sd_mecha_amd as amd  # noqa: E402
+from sd_mecha_amd.shapes import load_manifest, numel  # noqa: E402
+from sd_mecha_amd.streaming import OutSafetensorsDict, TensorMetadata  # noqa: E402
+
+WORKLOADS = {
+    # name: (manifest, components, n_models, recipe)
+    "sdxl_ties": ("sdxl-sgm", None, 4, "ties"),
+    "sdxl_navg": ("sdxl-sgm", None, 4, "navg"),
+    "sdxl_wsum": ("sdxl-sgm", None, 2, "wsum"),
+    "sd1_wsum": ("sd1-ldm", None, 2, "wsum"),
+}
+
+
+def write_checkpoint(path, manifest, seed, device):
+    header = {k: TensorMetadata(tuple(s), torch.bfloat16) for k, s, _ in manifest}
+    sink = OutSafetensorsDict(path, header, None)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    for k, s, _ in manifest:
+        t = torch.empty(max(numel(s), 1), dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)[:numel(s)]
+        sink[k] = t.view(tuple(s)).cpu()
+    sink.close()
+
+
+def link_rate(device, nbytes=1 << 30, reps=5):
+    h = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    out = {}
+    for name, (dst, src) in {"h2d": (d, h), "d2h": (h, d)}.items():
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 2)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="sdxl_ties", choices=sorted(WORKLOADS))
+    ap.add_argument("--dir", default="/dev/shm/mecha_e2e")
+    ap.add_argument("--buffer-gib", type=float, default=16.0, help="total_buffer_size of merge() (pinned staging budget)")
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    manifest_id, comps, n_models, recipe_kind = WORKLOADS[args.workload]
+    manifest = [(k, s, d) for k, s, d in load_manifest(manifest_id, comps) if not d.startswith("int")]
+    device = torch.device("cuda", 0)
+    work = pathlib.Path(args.dir)
+    work.mkdir(parents=True, exist_ok=True)
+    try:
+        t0 = time.perf_counter()
+        paths = []
+        for m in range(n_models):
+            p = work / f"m{m}.safetensors"
+            write_checkpoint(p, manifest, 100 + m, device)
+            paths.append(p)
+        gen_s = time.perf_counter() - t0
+        models = [amd.model(str(p)) for p in paths]
+        if recipe_kind == "ties":
+            deltas = [amd.subtract(m, models[0]) for m in models[1:]]
+            recipe = amd.add_difference(models[0], amd.ties_sum(*deltas, k=0.2), alpha=1.0) | models[0]
+        elif recipe_kind == "navg":
+            recipe = amd.n_average(*models)
+        else:
+            recipe = amd.weighted_sum(models[0], models[1], alpha=0.5)
+        elems = sum(numel(s) for _, s, _ in manifest)
+        moved = elems * 2 * (n_models + 1)
+        times = []
+        for r in range(args.reps):
+            out = work / "out.safetensors"
+            if out.exists():
+                out.unlink()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            amd.merge(recipe, output=str(out), output_dtype=torch.bfloat16, total_buffer_size=int(args.buffer_gib * 2 ** 30))
+            times.append(time.perf_counter() - t0)
+            from sd_mecha_amd import merging
+            print("phases (host seconds):", {k: round(v, 3) for k, v in merging.last_stats.items()}, file=sys.stderr, flush=True)
+        best = min(times)
+        line = {
+            "metric": "merged state-dict GB/s, end to end (files on tmpfs -> file on tmpfs)", "workload": args.workload,
+            "value": round(moved / best / 1e9, 2), "unit": "GB/s", "seconds": [round(t, 3) for t in times],
+            "bytes_moved": moved, "elements": elems, "keys": len(manifest), "n_models": n_models,
+            "total_buffer_size_gib": args.buffer_gib, "host_link_GBs": link_rate(device),
+            "link_bound_seconds": None, "cpu_count": os.cpu_count(), "generate_seconds": round(gen_s, 1),
+        }
+        lr = line["host_link_GBs"]
+        line["link_bound_seconds"] = round(max(elems * 2 * n_models / (lr["h2d"] * 1e9), elems * 2 / (lr["d2h"] * 1e9)), 3)
+        print(json.dumps(line), flush=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
