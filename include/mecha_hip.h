@@ -185,6 +185,32 @@ int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t col
                           const void *const *ups, const void *const *downs, const int32_t *ranks, const float *scales,
                           const float *weights, int n_networks, int lora_dtype, uint32_t *flags, void *stream);
 
+/* The same for every key of a batch in ONE launch (the reference evaluates one key per future,
+ * merging.py:223-229; a launch per key costs more than the key's tiles).  Base and output keys sit in
+ * two arenas at the same element offsets.  `keys` (DEVICE) / `keys_host` (HOST copy) hold n_keys
+ * entries; key i uses nets[net_begin .. net_begin + net_count) of the DEVICE table `nets`
+ * (net_count <= MECHA_MAX_MODELS; networks with weight 0 must be left out by the caller);
+ * tile_start = running sum of ceil(rows/64) * ceil(cols/64) over the keys before it.
+ * offset % 4 == 0 and cols % 4 == 0 enable the vector path.  `key_flags` (may be NULL): DEVICE
+ * uint32[n_keys]. */
+typedef struct mecha_lora_key {
+    int64_t offset;       /* first element of the key inside the base / output arenas */
+    int64_t rows, cols;   /* the key viewed as [out, in_flat] */
+    int64_t tile_start;
+    int32_t net_begin, net_count;
+} mecha_lora_key;
+typedef struct mecha_lora_net {
+    const void *up;       /* [rows, rank] */
+    const void *down;     /* [rank, cols] */
+    int32_t rank;
+    float scale, weight;
+    int32_t reserved;
+} mecha_lora_net;
+int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const mecha_lora_key *keys,
+                                  const mecha_lora_key *keys_host, int n_keys, const mecha_lora_net *nets,
+                                  int base_dtype, int out_dtype, int lora_dtype, uint32_t *key_flags,
+                                  void *stream);
+
 /* rotate (extensions/builtin/merge_methods/svd.py:10-86) at alignment = 1, alpha = 0 for one key already reshaped to
  * n_rows x n_cols (svd.py:49-53): centre both matrices by their column means * centralization (svd.py:67-70),
  * orthogonal_procrustes (svd.py:157-169; FullRankOrthogonalMatmul :194-206 for n_rows >= n_cols, LowRankOrthogonalMatmul

@@ -22,6 +22,18 @@ class Segment(ctypes.Structure):
     _fields_ = [("offset", ctypes.c_int64), ("numel", ctypes.c_int64)]
 
 
+class LoraKey(ctypes.Structure):
+    """mecha_lora_key"""
+    _fields_ = [("offset", ctypes.c_int64), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("tile_start", ctypes.c_int64),
+                ("net_begin", ctypes.c_int32), ("net_count", ctypes.c_int32)]
+
+
+class LoraNet(ctypes.Structure):
+    """mecha_lora_net"""
+    _fields_ = [("up", ctypes.c_void_p), ("down", ctypes.c_void_p), ("rank", ctypes.c_int32), ("scale", ctypes.c_float),
+                ("weight", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
 class MechaError(RuntimeError):
     """A libmecha_hip entry point returned a negative status."""
 
@@ -59,6 +71,7 @@ SIGNATURES = {
     "mecha_ties_sum_with_dropout": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_d, c_i, c_f, c_i, c_p, c_p, c_sz, c_p, c_p]),
     "mecha_dare_draw_masks_host": (c_i, [c_u64, c_f, c_i, c_i64, c_p]),
     "mecha_lora_accumulate": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "mecha_batched_lora_accumulate": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mecha_rotate_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "mecha_rotate": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p, c_p]),
     "mecha_allclose_half": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p]),

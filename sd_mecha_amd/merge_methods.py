@@ -419,6 +419,48 @@ def lora_merge(base: Optional[torch.Tensor], networks, target_shape=None, *, key
     return out
 
 
+class LoraBatch:
+    """The LoRA recipe for every key of a batch in ONE launch (mecha_batched_lora_accumulate): base and output keys live
+    in two arenas at the same element offsets.  ``entries``: ``[(offset, rows, cols, [(up, down, alpha, weight), ...])]``
+    with offsets in elements; the descriptor tables are built once and reused by every ``run``."""
+
+    def __init__(self, entries, device):
+        keys, nets, self._keep = [], [], []
+        tile = 0
+        self.lora_dtype = None
+        for offset, rows, cols, networks in entries:
+            begin = len(nets)
+            for up, down, alpha, w in networks:
+                if math.isclose(float(w), 0.0):
+                    continue                                            # add_difference alpha == 0 returns `a` (linear.py:72-73)
+                up2, down2, rank, scale = _lora_network(up, down, alpha)
+                if up2.shape[0] != rows or down2.shape[1] != cols:
+                    raise ValueError(f"a network of the key at offset {offset} does not produce {rows} x {cols}")
+                if up2.dtype not in (torch.float16, torch.bfloat16) or down2.dtype != up2.dtype or (self.lora_dtype or up2.dtype) != up2.dtype:
+                    raise NotImplementedError("LoRA factors of one batch must share one of float16 / bfloat16")
+                self.lora_dtype = up2.dtype
+                self._keep += [up2, down2]
+                nets.append(_lib.LoraNet(up2.data_ptr(), down2.data_ptr(), rank, scale, float(w), 0))
+            if len(nets) - begin > _lib.MAX_MODELS:
+                raise ValueError(f"at most {_lib.MAX_MODELS} networks per key")
+            keys.append(_lib.LoraKey(int(offset), int(rows), int(cols), tile, begin, len(nets) - begin))
+            tile += ((cols + 63) // 64) * ((rows + 63) // 64)
+        self.n_keys = len(keys)
+        self.keys_host = (_lib.LoraKey * max(len(keys), 1))(*keys)
+        nets_host = (_lib.LoraNet * max(len(nets), 1))(*nets)
+        self.keys_dev = torch.frombuffer(bytearray(bytes(self.keys_host)), dtype=torch.uint8).to(device)
+        self.nets_dev = torch.frombuffer(bytearray(bytes(nets_host)), dtype=torch.uint8).to(device)
+
+    def run(self, base_arena: Optional[torch.Tensor], out_arena: torch.Tensor, key_flags: Optional[torch.Tensor] = None) -> None:
+        if self.n_keys == 0:
+            return
+        _lib.check(_lib.lib().mecha_batched_lora_accumulate(
+            base_arena.data_ptr() if base_arena is not None else None, out_arena.data_ptr(), self.keys_dev.data_ptr(),
+            ctypes.addressof(self.keys_host), self.n_keys, self.nets_dev.data_ptr(),
+            _DT[base_arena.dtype] if base_arena is not None else F32, _DT[out_arena.dtype], _DT[self.lora_dtype or torch.float16],
+            key_flags.data_ptr() if key_flags is not None else None, _stream()), "mecha_batched_lora_accumulate")
+
+
 # ------------------------------------------------------------------ svd.py
 def rotate_shape_2d(shape) -> tuple:
     """svd.py:49-53: conv k x k keys flatten to (out * in, kh * kw), everything else to (out, rest)."""

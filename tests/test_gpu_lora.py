@@ -69,6 +69,45 @@ def test_lora_many_networks_vs_oracle(oracle, ldt):
         assert np.allclose(got32, acc, rtol=2e-5, atol=1e-7)
 
 
+def test_lora_batched_matches_per_key():
+    """Every key of a batch in one launch (mecha_batched_lora_accumulate) gives, bit for bit, what the per-key entry
+    point gives; gaps between keys stay untouched; a non-finite factor flags its own key only."""
+    import sd_mecha_amd as amd
+    from sd_mecha_amd import merge_methods as mm
+    from sd_mecha_amd.arena import plan_arena
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(320, 320), (77, 131), (64, 32, 3, 3), (1280, 640), (5, 9), (640, 2560)]
+    layout = plan_arena([(f"k{i}", int(np.prod(s))) for i, s in enumerate(shapes)])
+    base = (torch.randn(layout.total_elems, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    out = torch.full((layout.total_elems,), 7.0, dtype=torch.bfloat16, device="cuda")
+    entries, per_key = [], []
+    for i, (s, off) in enumerate(zip(shapes, layout.offsets)):
+        rows, cols = s[0], int(np.prod(s)) // s[0]
+        nets = []
+        for r in ([32, 32, 8], [4], [16, 5], [32] * 16, [3], [64, 32])[i]:
+            up = (torch.randn(rows, r, device="cuda", generator=g) * 0.05).half()
+            down = (torch.randn(r, cols, device="cuda", generator=g) * 0.05).half()
+            nets.append((up, down, float(r) / 2, 0.0 if (i == 3 and len(nets) == 5) else 0.8))
+        if i == 4:
+            nets[0][0][2, 1] = float("inf")
+        entries.append((off, rows, cols, nets))
+        per_key.append(None if i == 4 else amd.lora_merge(base[off:off + rows * cols].view(rows, cols), nets, out_dtype=torch.bfloat16))
+    flags = torch.zeros(len(shapes), dtype=torch.int32, device="cuda")
+    batch = mm.LoraBatch(entries, torch.device("cuda"))
+    for _ in range(2):
+        flags.zero_()
+        batch.run(base, out, flags)
+    torch.cuda.synchronize()
+    assert [int(f) & 1 for f in flags.cpu()] == [0, 0, 0, 0, 1, 0]
+    covered = torch.zeros(layout.total_elems, dtype=torch.bool, device="cuda")
+    for i, (s, off) in enumerate(zip(shapes, layout.offsets)):
+        n = int(np.prod(s))
+        covered[off:off + n] = True
+        if per_key[i] is not None:
+            assert torch.equal(out[off:off + n], per_key[i].reshape(-1)), i
+    assert (out[~covered] == 7.0).all()
+
+
 def test_lora_conv_shapes_and_validation():
     import sd_mecha_amd as amd
     up = torch.randn(32, 8, 1, 1, device="cuda").half()

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Per-key methods on MI355X at the sizes of BASELINE configs 4 and 5, tensors resident in HBM:
+
+    python tools/bench_keys.py --workload sdxl_rotate [--key-stride 8]    # svd.rotate(a, b, alignment=1, alpha=0) on every >=2-D key
+    python tools/bench_keys.py --workload sdxl_lora                        # base + sum of 16 rank-32 fp16 LoRA deltas, every >=2-D key
+
+One JSON line per run: merged GB/s (inputs + output of the merged keys over wall time), the MFMA roofline of the
+dominant GEMM kernel from the library's HIP-event timers, and for rotate the Jacobi sweep counts and time.
+bench.py stays the bench of record for the streaming / TIES path; this tool covers the two MFMA-bound rows."""
+import argparse
+import json
+import pathlib
+import sys
+import time
+
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from sd_mecha_amd import _lib  # noqa: E402
+from sd_mecha_amd import merge_methods as mm  # noqa: E402
+from sd_mecha_amd.shapes import load_manifest, numel  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+F16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA peak
+
+
+def eligible(manifest):
+    return [(k, tuple(s)) for k, s, d in manifest if not d.startswith("int") and len(s) >= 2 and numel(s) > 0]
+
+
+def rotate_flops(n, p):
+    """tall keys 2np^2 (A^T B) + 2p^3 (U V^T) + 2np^2 (X R); wide keys (n < p) work on the n x n side."""
+    if n >= p:
+        return 2 * n * p * p + 2 * p ** 3 + 2 * n * p * p
+    return 2 * n * n * p + 2 * n ** 3 + 2 * n * n * p
+
+
+def run_rotate(args, device):
+    keys = eligible(load_manifest("sdxl-sgm"))
+    keys.sort(key=lambda kv: -numel(kv[1]))
+    keys = keys[::args.key_stride]
+    gen = torch.Generator(device=device).manual_seed(7)
+    sweeps_all, done_bytes, flops, skipped = [], 0, 0, 0
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    t_total = 0.0
+    for k, shape in keys:
+        n, p = mm.rotate_shape_2d(shape)
+        if min(n, p) > 8192:
+            skipped += 1
+            continue
+        a = torch.empty(shape, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
+        b = torch.empty(shape, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, sweeps = mm.rotate(a, b, alignment=1.0, alpha=0.0, out_dtype=torch.bfloat16, return_sweeps=True)
+        torch.cuda.synchronize()
+        t_total += time.perf_counter() - t0
+        sweeps_all.append(sweeps)
+        done_bytes += numel(shape) * 2 * 3
+        flops += rotate_flops(n, p)
+        del a, b, out
+    kernels = _lib.profile_read()
+    _lib.profile_enable(False)
+    gemm_ms = kernels.get("rotate_gemm_f32mfma", (0.0, 1))[0]
+    jac_ms = kernels.get("rotate_jacobi_step", (0.0, 1))[0]
+    achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
+    return {
+        "metric": "merged state-dict GB/s", "value": round(done_bytes / t_total / 1e9, 3), "unit": "GB/s", "n_gpus": 1,
+        "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "sdxl_rotate", "description": "SDXL svd.rotate(a, b, alignment=1.0, alpha=0.0) per >=2-D key of 2 random-init bf16 checkpoints, bf16 out",
+                   "keys": len(sweeps_all), "key_stride": args.key_stride, "keys_skipped_too_large": skipped},
+        "seconds": round(t_total, 3), "keys_per_second": round(len(sweeps_all) / t_total, 2),
+        "roofline": {"bound": "mfma", "kernel": "rotate_gemm_f32mfma", "achieved": round(achieved, 2) if achieved else None,
+                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                     "traffic": None, "algorithmic_flops": flops, "kernel_ms_total": round(gemm_ms, 2)},
+        "jacobi": {"ms_total": round(jac_ms, 2), "sweeps_mean": round(sum(sweeps_all) / max(len(sweeps_all), 1), 2),
+                   "sweeps_max": max(sweeps_all, default=0)},
+        "kernels": {k: {"ms_total": round(ms, 2), "launches": n} for k, (ms, n) in kernels.items()},
+    }
+
+
+def run_lora(args, device):
+    keys = eligible(load_manifest("sdxl-sgm"))
+    keys = keys[::args.key_stride]
+    n_nets, rank = 16, 32
+    gen = torch.Generator(device=device).manual_seed(11)
+    from sd_mecha_amd.arena import plan_arena
+    layout = plan_arena([(k, numel(s)) for k, s in keys])
+    base_arena = torch.empty(layout.total_elems, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
+    out_arena = torch.zeros(layout.total_elems, dtype=torch.bfloat16, device=device)
+    flags = torch.zeros(len(keys), dtype=torch.int32, device=device)
+    job, entries = [], []
+    for (k, shape), off in zip(keys, layout.offsets):
+        rows, cols = shape[0], numel(shape) // shape[0]
+        nets = []
+        for _ in range(n_nets):
+            up = torch.empty((rows, rank), dtype=torch.float16, device=device).normal_(0.0, 0.02, generator=gen)
+            down = torch.empty((rank, cols), dtype=torch.float16, device=device).normal_(0.0, 0.02, generator=gen)
+            nets.append((up, down, 16.0, 1.0))
+        job.append((None, nets, rows, cols))
+        entries.append((off, rows, cols, nets))
+    batch = mm.LoraBatch(entries, device)
+
+    def step():
+        flags.zero_()
+        batch.run(base_arena, out_arena, flags)
+        if int((flags & 1).sum().item()):
+            raise RuntimeError("keys flagged non-finite on finite synthetic inputs")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = (time.perf_counter() - t0) / args.steps
+    kernels = _lib.profile_read()
+    _lib.profile_enable(False)
+    flops = sum(2 * r * c * rank * n_nets for _, _, r, c in job)
+    moved = sum(r * c * 2 * 2 + n_nets * (r + c) * rank * 2 for _, _, r, c in job)
+    ms, launches = kernels.get("lora_mfma", (0.0, 1))
+    per_step_ms = ms / args.steps
+    achieved = flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms else None
+    return {
+        "metric": "merged state-dict GB/s", "value": round(moved / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "sdxl_lora", "description": "SDXL base (bf16) + sum of 16 rank-32 fp16 LoRA deltas (alpha=16, weight 1.0) on every >=2-D key, bf16 out",
+                   "keys": len(job), "key_stride": args.key_stride, "bytes_per_step": moved},
+        "roofline": {"bound": "hbm", "kernel": "lora_mfma", "achieved": round(moved / (per_step_ms * 1e-3) / 1e9, 1) if per_step_ms else None,
+                     "peak": 8000.0, "unit": "GB/s", "frac": round(moved / (per_step_ms * 1e-3) / 1e9 / 8000.0, 4) if per_step_ms else None,
+                     "traffic": None, "kernel_ms_per_step": round(per_step_ms, 3),
+                     "mfma_TFLOPs": round(achieved, 2) if achieved else None, "mfma_frac_of_dense_f16_peak": round(achieved / F16_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                     "note": "rank-32 reconstruction has 2*32/(2*2) = 16 flop per output byte: far below the MFMA ridge, so HBM bounds it"},
+        "kernels": {k: {"ms_total": round(v[0], 2), "launches": v[1]} for k, v in kernels.items()},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", required=True, choices=["sdxl_rotate", "sdxl_lora"])
+    ap.add_argument("--key-stride", type=int, default=1, help="take every n-th eligible key (largest first for rotate)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "needs a GPU"
+    device = torch.device("cuda", 0)
+    line = run_rotate(args, device) if args.workload == "sdxl_rotate" else run_lora(args, device)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
