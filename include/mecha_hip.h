@@ -214,11 +214,12 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
 /* rotate (extensions/builtin/merge_methods/svd.py:10-86) at alignment = 1, alpha = 0 for one key already reshaped to
  * n_rows x n_cols (svd.py:49-53): centre both matrices by their column means * centralization (svd.py:67-70),
  * orthogonal_procrustes (svd.py:157-169; FullRankOrthogonalMatmul :194-206 for n_rows >= n_cols, LowRankOrthogonalMatmul
- * :172-191 otherwise) with the A^T B contraction on f32 MFMA and the SVD as a one-sided Jacobi, apply the transform to
- * the centred `a`, add b's mean (svd.py:84-85).  n_cols <= 8192.  The early-outs of svd.py:37-47 stay in the host shim
- * (mecha_allclose_half implements the torch.allclose(a.half(), b.half()) test of :46).
- * SYNCHRONISES `stream` once per Jacobi sweep (it reads one convergence counter).  `sweeps_out` (HOST int, may be NULL)
- * receives the number of sweeps. */
+ * :172-191 otherwise) with every contraction on f32 MFMA; U V^T of the reference's SVD is computed as the orthogonal
+ * polar factor by Newton-Schulz iterations (GEMMs only, no SVD); apply the transform to the centred `a`, add b's mean
+ * (svd.py:84-85).  The early-outs of svd.py:37-47 stay in the host shim (mecha_allclose_half implements the
+ * torch.allclose(a.half(), b.half()) test of :46).
+ * SYNCHRONISES `stream` once per iteration (it reads the convergence measure).  `sweeps_out` (HOST int, may be NULL)
+ * receives the number of Newton-Schulz iterations (summed over the key's polar solves: 1 for tall, 2 for wide keys). */
 size_t mecha_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols);
 int mecha_rotate(const void *a, const void *b, void *out, int64_t n_rows, int64_t n_cols, int in_dtype, int out_dtype,
                  float centralization, void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);

@@ -42,7 +42,7 @@ static inline bool mecha_aligned16(const void *p) { return (reinterpret_cast<uin
 // stream; mecha_profile_read sums the elapsed times per kernel family.  bench.py uses this for `roofline`.
 enum MechaKernelId : int {
     MK_STREAMING = 0, MK_TIES_INDEX, MK_TIES_HIST1, MK_TIES_HIST2, MK_TIES_HIST3, MK_TIES_SCAN, MK_TIES_MERGE,
-    MK_RED_REDUCE, MK_RED_FINISH, MK_RED_APPLY, MK_RED_FIXUP, MK_LORA, MK_ROT_GEMM, MK_ROT_JACOBI,
+    MK_RED_REDUCE, MK_RED_FINISH, MK_RED_APPLY, MK_RED_FIXUP, MK_LORA, MK_ROT_GEMM, MK_ROT_NORMS,
     MK_TIES_SAMPLE, MK_TIES_COUNT, MK_TIES_RESOLVE, MK_TIES_FIXUP, MK_COUNT
 };
 extern bool g_mecha_profiling;

@@ -8,20 +8,22 @@
 //             out = Ac - (Ac V) V^T + (Ac U) V^T + b_mean                                             (svd.py:160-163, :181)
 //   lerp(a_mean, b_mean, alignment = 1) = b_mean exactly (Lerp.h: weight >= 0.5 branch, fma(0, d, b)).
 //
+// The transform only ever uses U V^T, never U, S or V on their own: U V^T is the orthogonal POLAR FACTOR of the matrix, and
+// the polar factor is reachable with matrix products alone (Newton-Schulz, polar_newton_schulz below).  So there is no SVD
+// here: every step is a GEMM on the matrix cores.  (A one-sided Jacobi SVD, the first version of this file, spent > 99 % of
+// a key's time in ~25 000 tiny dependent launches per 1280 x 1280 key.)  The same iteration gives the orthonormal basis Qb
+// of the wide case (polar factor of Bc) and U W^T (polar factor of N); with Z = polar(N^T):  U V^T = Z^T Qb^T.
+//
 // Kernels
 //   rot_colsum / rot_means / rot_center : column means (fp64 accumulation) and the centred fp32 copies Ac, Bc
 //   gemm_kernel   : C[m][n] = sum_k A(k, m) B(k, n) with arbitrary element strides, on v_mfma_f32_32x32x2_f32 (exact fp32
 //                   fma chains); split-K slabs + an in-order reduce for skinny outputs (conv 3x3 keys: p = 9, n ~ 1.6 M);
-//                   fused epilogue (minus / plus a matrix, per-column bias, cast to the output dtype, finite flag)
-//   jacobi_step   : one-sided (Hestenes) Jacobi SVD.  The vectors being orthogonalised are stored as ROWS, so each is
-//                   contiguous; a step rotates c/2 disjoint pairs in parallel (round-robin ordering), one workgroup per
-//                   pair: both vectors are staged in registers, the three inner products reduced through LDS, and the
-//                   pair of vectors and the matching pair of rows of W^T rotated.  A sweep is c - 1 steps; sweeps repeat
-//                   until one makes no rotation (the host reads one counter per sweep).
-//   rot_normalize : U = G / |column|
-// The SVD's sign/order ambiguity cancels in U V^T; parity with the reference is <= 1e-3 relative Frobenius error
-// (wide keys with centring: on the component the reference determines, DESIGN.md "rotate: reference indeterminacy").
-// Roofline: MFMA (f32) for the GEMMs (2 n p^2 flop each), LDS/latency for the Jacobi sweeps (reported as sweeps + time).
+//                   fused epilogue (a X + b C update, minus / plus a matrix, per-column bias, cast to the output dtype, flag)
+//   rot_gram_norms: |G|_F^2 and |G - I|_F^2 of the Gram matrix, the convergence measure the host reads once per iteration
+// The SVD's sign/order ambiguity does not exist for the polar factor; parity with the reference is <= 1e-3 relative
+// Frobenius error (wide keys with centring: on the component the reference determines, DESIGN.md "rotate: reference
+// indeterminacy").  Roofline: MFMA (f32).  Flops, with q = min(n, p), c = max over the polar solves' column count:
+// 2 n p^2 for each of the A^T B contraction and the final application, 4 q^2 c per Newton-Schulz iteration.
 #include <type_traits>
 #include "common.h"
 
@@ -91,10 +93,13 @@ struct GemmEpilogue {
     void *out;                  // if set: write v in out_dt (and raise the finite flag); else fp32 C
     int out_dt;
     uint32_t *flags;
+    const float *axpy;          // if set: v = axpy_a * axpy[idx] + axpy_b * v   (the Newton-Schulz update), applied first
+    float axpy_a, axpy_b;
 };
 
 __device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int64_t ldc, int64_t row, int64_t col, float v, bool &bad) {
     const int64_t idx = row * ldc + col;
+    if (e.axpy != nullptr) v = __builtin_fmaf(e.axpy_a, e.axpy[idx], e.axpy_b * v);
     if (e.minus != nullptr) v = v - e.minus[idx];
     if (e.plus != nullptr) v = e.plus[idx] + v;
     if (e.col_bias != nullptr) v = v + e.col_bias[col];
@@ -106,36 +111,98 @@ __device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int6
     } else c[idx] = v;
 }
 
+// One operand tile (GK k-values x 64 m-values) of the block: 8 floats per thread, loaded with 16-byte accesses along whichever
+// of the two directions is contiguous in memory, and stored to LDS as [k][m] (what the MFMA lanes read: one float each,
+// 32 consecutive m per half-wave).
+constexpr int GK = 32;                 // k-chunk per LDS buffer
+constexpr int GP = 68;                 // LDS row pitch in floats (272 B: 16-byte aligned rows, rows 4 banks apart)
+struct TileRegs { f32x4 v[2]; };
+
+__device__ __forceinline__ TileRegs tile_load(const Operand &op, int64_t m0, int64_t M, int64_t k0, int64_t k_end) {
+    TileRegs t;
+    const int tid = threadIdx.x;
+    if (op.ms == 1) {                  // m-contiguous: thread = (k = tid / 16 [+16], 4 consecutive m)
+        const int64_t m = m0 + (tid & 15) * 4;
+        const bool vec = ((op.ks & 3) == 0) && (m + 4 <= M) && ((reinterpret_cast<uintptr_t>(op.p) & 15u) == 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int64_t k = k0 + (tid >> 4) + 16 * h;
+            if (k < k_end && vec) t.v[h] = *reinterpret_cast<const f32x4 *>(op.p + k * op.ks + m);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) t.v[h][j] = (k < k_end && m + j < M) ? op.p[k * op.ks + m + j] : 0.0f;
+            }
+        }
+    } else if (op.ks == 1) {           // k-contiguous: thread = (m = tid % 64, 4 consecutive k at 4 * (tid / 64) [+16])
+        const int64_t m = m0 + (tid & 63);
+        const bool vec = ((op.ms & 3) == 0) && ((k0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(op.p) & 15u) == 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int64_t k = k0 + 4 * (tid >> 6) + 16 * h;
+            if (m < M && k + 4 <= k_end && vec) t.v[h] = *reinterpret_cast<const f32x4 *>(op.p + m * op.ms + k);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) t.v[h][j] = (m < M && k + j < k_end) ? op.p[m * op.ms + k + j] : 0.0f;
+            }
+        }
+    } else {                           // neither: element (k, m) = (e / 64, e % 64), e = tid + 256 j
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + 256 * j;
+            const int64_t k = k0 + (e >> 6), m = m0 + (e & 63);
+            t.v[j >> 2][j & 3] = (k < k_end && m < M) ? op.p[k * op.ks + m * op.ms] : 0.0f;
+        }
+    }
+    return t;
+}
+__device__ __forceinline__ void tile_store(const Operand &op, const TileRegs &t, float *lds) {
+    const int tid = threadIdx.x;
+    if (op.ms == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) *reinterpret_cast<f32x4 *>(&lds[((tid >> 4) + 16 * h) * GP + (tid & 15) * 4]) = t.v[h];
+    } else if (op.ks == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds[(4 * (tid >> 6) + 16 * h + j) * GP + (tid & 63)] = t.v[h][j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + 256 * j;
+            lds[(e >> 6) * GP + (e & 63)] = t.v[j >> 2][j & 3];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab,
                                                    GemmEpilogue e) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][GK * GP];       // [buffer][A | B]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kk = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * 64 + (wave >> 1) * 32, n0 = (int64_t)blockIdx.x * 64 + (wave & 1) * 32;
-    if (m0 >= M || n0 >= N) return;
+    const int64_t bm0 = (int64_t)blockIdx.y * 64, bn0 = (int64_t)blockIdx.x * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int64_t m0 = bm0 + wm, n0 = bn0 + wn;
     const int64_t k_begin = (int64_t)blockIdx.z * k_per_slab;
     const int64_t k_end = (k_begin + k_per_slab < K) ? k_begin + k_per_slab : K;
-    const bool a_ok = m0 + i < M, b_ok = n0 + i < N;
-    const float *ap = A.p + (m0 + i) * A.ms, *bp = B.p + (n0 + i) * B.ms;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    int64_t k = k_begin;
-    for (; k + 16 <= k_end; k += 16) {
-        float av[8], bv[8];
+    // software pipeline: the next chunk's global loads are in flight while the MFMAs consume the current LDS buffer
+    TileRegs ra = tile_load(A, bm0, M, k_begin, k_end), rb = tile_load(B, bn0, N, k_begin, k_end);
+    tile_store(A, ra, lds[0][0]);
+    tile_store(B, rb, lds[0][1]);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k = k_begin; k < k_end; k += GK) {
+        const bool more = k + GK < k_end;
+        if (more) { ra = tile_load(A, bm0, M, k + GK, k_end); rb = tile_load(B, bn0, N, k + GK, k_end); }
+        const float *la = lds[buf][0] + wm + i, *lb = lds[buf][1] + wn + i;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int64_t kr = k + 2 * u + kk;
-            av[u] = a_ok ? ap[kr * A.ks] : 0.0f;
-            bv[u] = b_ok ? bp[kr * B.ks] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-    }
-    for (; k < k_end; k += 2) {
-        const int64_t kr = k + kk;
-        const float av = (a_ok && kr < k_end) ? ap[kr * A.ks] : 0.0f;
-        const float bv = (b_ok && kr < k_end) ? bp[kr * B.ks] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int u = 0; u < GK / 2; u++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(la[(2 * u + kk) * GP], lb[(2 * u + kk) * GP], acc, 0, 0, 0);
+        if (more) { tile_store(A, ra, lds[buf ^ 1][0]); tile_store(B, rb, lds[buf ^ 1][1]); }
+        __syncthreads();
+        buf ^= 1;
     }
     float *c = C + (int64_t)blockIdx.z * M * N;
     GemmEpilogue ee = e;
@@ -161,87 +228,26 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
     if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
-// ------------------------------------------------------------------------------------------------ one-sided Jacobi
-constexpr int JAC_MAX_REG = 32;       // floats of each vector a lane keeps in registers (length <= 8192)
-constexpr int64_t JAC_MAX_LEN = (int64_t)JAC_MAX_REG * 256;
-
-__global__ __launch_bounds__(256) void set_identity_kernel(float *w, int64_t c) {
-    const int64_t total = c * c;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) w[i] = (i / c == i % c) ? 1.0f : 0.0f;
-}
-
-// Round-robin pairing of `players` (even) vectors at step s: player players-1 is fixed, the rest rotate.
-__device__ __forceinline__ void jacobi_pair(int players, int s, int k, int &i, int &j) {
-    const int m = players - 1;
-    if (k == 0) { i = m; j = s % m; }
-    else { i = (s + k) % m; j = (s - k + m) % m; }
-    if (i > j) { const int t = i; i = j; j = t; }
-}
-
-__device__ __forceinline__ float block_sum(float v, float *sh) {
+// ------------------------------------------------------------------------------------------------ polar factor
+// scal[0] += sum G^2, scal[1] += sum (G - I)^2 over the r x r Gram matrix G (fp64 accumulation; scal zeroed by the host)
+__global__ __launch_bounds__(256) void rot_gram_norms_kernel(const float *g, int64_t r, double *scal) {
+    __shared__ double sh[2][4];
+    const int64_t total = r * r;
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)g[i];
+        const double d = v - ((i / r == i % r) ? 1.0 : 0.0);
+        s0 += v * v; s1 += d * d;
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = s0; sh[1][wave] = s1; }
     __syncthreads();
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-// gt: c vectors of length m (rows), wt: c x c (row k = column k of W).  One block per pair.
-__global__ __launch_bounds__(256) void jacobi_step_kernel(float *gt, float *wt, int c, int64_t m, int players, int step, float tol,
-                                                          unsigned int *rotations) {
-    int i, j;
-    jacobi_pair(players, step, blockIdx.x, i, j);
-    if (j >= c) return;                                         // pair with the padding player (odd c)
-    __shared__ float sh[4];
-    __shared__ float rot[2];
-    float *gi = gt + (int64_t)i * m, *gj = gt + (int64_t)j * m;
-    float xi[JAC_MAX_REG], xj[JAC_MAX_REG];
-    float aa = 0.0f, bb = 0.0f, ab = 0.0f;
-#pragma unroll
-    for (int u = 0; u < JAC_MAX_REG; u++) {
-        const int64_t t = (int64_t)u * 256 + threadIdx.x;
-        xi[u] = (t < m) ? gi[t] : 0.0f;
-        xj[u] = (t < m) ? gj[t] : 0.0f;
-        aa = __builtin_fmaf(xi[u], xi[u], aa); bb = __builtin_fmaf(xj[u], xj[u], bb); ab = __builtin_fmaf(xi[u], xj[u], ab);
-    }
-    aa = block_sum(aa, sh); bb = block_sum(bb, sh); ab = block_sum(ab, sh);
     if (threadIdx.x == 0) {
-        float cs = 1.0f, sn = 0.0f;
-        if (__builtin_fabsf(ab) > tol * __builtin_sqrtf(aa * bb) && ab != 0.0f) {
-            const float zeta = (bb - aa) / (2.0f * ab);
-            const float t = ((zeta >= 0.0f) ? 1.0f : -1.0f) / (__builtin_fabsf(zeta) + __builtin_sqrtf(1.0f + zeta * zeta));
-            cs = 1.0f / __builtin_sqrtf(1.0f + t * t);
-            sn = cs * t;
-            atomicAdd(rotations, 1u);
-        }
-        rot[0] = cs; rot[1] = sn;
+        atomicAdd(&scal[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(&scal[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
     }
-    __syncthreads();
-    const float cs = rot[0], sn = rot[1];
-    if (sn == 0.0f) return;
-#pragma unroll
-    for (int u = 0; u < JAC_MAX_REG; u++) {
-        const int64_t t = (int64_t)u * 256 + threadIdx.x;
-        if (t < m) { gi[t] = cs * xi[u] - sn * xj[u]; gj[t] = sn * xi[u] + cs * xj[u]; }
-    }
-    float *wi = wt + (int64_t)i * c, *wj = wt + (int64_t)j * c;
-    for (int t = threadIdx.x; t < c; t += 256) {
-        const float a = wi[t], b = wj[t];
-        wi[t] = cs * a - sn * b; wj[t] = sn * a + cs * b;
-    }
-}
-
-// each row of gt scaled to unit norm (U = G / sigma); an exactly-zero vector stays zero
-__global__ __launch_bounds__(256) void rot_normalize_kernel(float *gt, int64_t m) {
-    __shared__ float sh[4];
-    float *g = gt + (int64_t)blockIdx.x * m;
-    float s = 0.0f;
-    for (int64_t t = threadIdx.x; t < m; t += 256) s = __builtin_fmaf(g[t], g[t], s);
-    s = block_sum(s, sh);
-    const float inv = (s > 0.0f) ? 1.0f / __builtin_sqrtf(s) : 0.0f;
-    for (int64_t t = threadIdx.x; t < m; t += 256) g[t] = g[t] * inv;
 }
 
 // torch.allclose(a.half(), b.half())  (svd.py:46): |a - b| <= 1e-8 + 1e-5 |b| on the fp16-rounded values
@@ -295,40 +301,68 @@ void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, float
     }
 }
 
-// One-sided Jacobi on the c vectors (rows of gt, length m); wt = accumulated right rotations (as rows).
-// Synchronises the stream once per sweep to read the rotation counter.
-int jacobi_svd(float *gt, float *wt, int c, int64_t m, unsigned int *counter_dev, int max_sweeps, int *sweeps_out, hipStream_t s) {
-    MECHA_REQUIRE(m <= JAC_MAX_LEN, "rotate: vector length %lld exceeds the Jacobi register window (%lld)", (long long)m, (long long)JAC_MAX_LEN);
-    const unsigned ib = (unsigned)(((int64_t)c * c + 255) / 256 < 2048 ? ((int64_t)c * c + 255) / 256 : 2048);
-    hipLaunchKernelGGL(set_identity_kernel, dim3(ib), dim3(256), 0, s, wt, (int64_t)c);
-    const int players = (c + 1) / 2 * 2;
-    const float tol = 1e-6f;
-    int sweeps = 0;
-    if (c >= 2) {
-        while (sweeps < max_sweeps) {
-            MECHA_CHECK_HIP(hipMemsetAsync(counter_dev, 0, sizeof(unsigned int), s));
-            for (int step = 0; step < players - 1; step++)
-                MECHA_LAUNCH(MK_ROT_JACOBI, jacobi_step_kernel, dim3(players / 2), dim3(256), 0, s, gt, wt, c, m, players, step, tol, counter_dev);
-            unsigned int rotations = 0;
-            MECHA_CHECK_HIP(hipMemcpyAsync(&rotations, counter_dev, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-            MECHA_CHECK_HIP(hipStreamSynchronize(s));
-            sweeps++;
-            if (rotations == 0) break;
+// Orthogonal polar factor of X (r x c row-major, r <= c), in place: X = U S V^T  ->  U V^T (zero singular values stay zero).
+// Newton-Schulz with the degree-5 polynomial  X <- a X + (b G + c G^2) X,  G = X X^T,  (a, b, c) = (2.5, -2.5, 1):
+// f(s) = 2.5 s - 2.5 s^3 + s^5 has f(1) = 1, f'(1) = 0 (quadratic convergence, converged values stay put), slope 2.5 at 0
+// (a small singular value grows 2.5x per iteration instead of the cubic iteration's 1.5x, for one extra r x r x r GEMM) and
+// maps (0, 1] into (0, 1.061], inside the basin of attraction.  X is scaled once by |X X^T|_F^(-1/2) <= 1 / sigma_max so
+// that every singular value starts in (0, 1]; the iteration count is about log_2.5(cond) + 4.  The host reads |G - I|_F^2
+// once per iteration and stops at 1e-7, at the fp32 noise floor, or -- after the iterations that lift anything above
+// 1e-7 sigma_max to O(1) -- on a plateau at a whole number (that many singular values are numerically zero: rank-
+// deficient input, e.g. a centred square key; the reference's LAPACK leaves those directions to rounding noise too).
+// tmp: r x c, G and G2: r x r, scal: device double[2].
+int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, int64_t c, double *scal, float *slabs, int max_iters,
+                        int *iters_out, hipStream_t s) {
+    float *cur = X, *nxt = tmp;
+    const int64_t rr = r * r;
+    const unsigned nb = (unsigned)((rr + 255) / 256 < 1024 ? (rr + 255) / 256 : 1024);
+    const GemmEpilogue none{};
+    double prev_dev2 = 0.0;
+    int it = 0;
+    for (; it < max_iters; it++) {
+        // G[m][n] = sum_k cur[m][k] cur[n][k]
+        gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, slabs, none, s);
+        MECHA_CHECK_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), s));
+        MECHA_LAUNCH(MK_ROT_NORMS, rot_gram_norms_kernel, dim3(nb), dim3(256), 0, s, G, r, scal);
+        double h[2] = {0.0, 0.0};
+        MECHA_CHECK_HIP(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, s));
+        MECHA_CHECK_HIP(hipStreamSynchronize(s));
+        double a = 2.5, b = -2.5, cc = 1.0;
+        if (it == 0) {
+            if (!(h[0] > 0.0) || h[0] != h[0] || h[0] > 1e300) break;       // zero (or non-finite) matrix: nothing to orthogonalise
+            const double scale = 1.0 / sqrt(sqrt(h[0]));                    // 1 / |G|_F^(1/2); G below is the unscaled Gram matrix
+            const double s2 = scale * scale;
+            a *= scale; b *= scale * s2; cc *= scale * s2 * s2;
+        } else {
+            const double dev2 = h[1];
+            if (dev2 <= 1e-7) break;
+            if (it > 1 && dev2 < 1e-4 && dev2 > 0.5 * prev_dev2) break;    // at the noise floor
+            const double whole = floor(dev2 + 0.5);
+            if (it >= 24 && whole >= 1.0 && fabs(dev2 - whole) < 1e-3 && fabs(dev2 - prev_dev2) < 1e-4) break;   // numerically rank-deficient
+            prev_dev2 = dev2;
         }
+        // G2 = b G + c G G;  nxt = a cur + G2 cur
+        GemmEpilogue mix{};
+        mix.axpy = G; mix.axpy_a = (float)b; mix.axpy_b = (float)cc;
+        gemm(Operand{G, 1, r}, Operand{G, r, 1}, G2, r, r, r, slabs, mix, s);
+        GemmEpilogue upd{};
+        upd.axpy = cur; upd.axpy_a = (float)a; upd.axpy_b = 1.0f;
+        gemm(Operand{G2, 1, r}, Operand{cur, c, 1}, nxt, r, c, r, slabs, upd, s);
+        float *t = cur; cur = nxt; nxt = t;
     }
-    if (sweeps_out) *sweeps_out += sweeps;
-    hipLaunchKernelGGL(rot_normalize_kernel, dim3(c), dim3(256), 0, s, gt, m);
+    if (iters_out) *iters_out += it;
+    if (cur != X) MECHA_CHECK_HIP(hipMemcpyAsync(X, cur, sizeof(float) * r * c, hipMemcpyDeviceToDevice, s));
     return MECHA_OK;
 }
 
 size_t rotate_workspace_bytes_impl(int64_t n, int64_t p) {
-    const size_t q = (size_t)(n < p ? n : p);                   // number of vectors the Jacobi runs on
+    const size_t q = (size_t)(n < p ? n : p);
     size_t b = 4096;
     b += up256(sizeof(double) * 2 * 64 * p) + 2 * up256(sizeof(float) * p);
     b += 2 * up256(sizeof(float) * n * p);                      // Ac, Bc
     b += up256(sizeof(float) * SLAB_FLOATS);
-    if (n >= p) b += 3 * up256(sizeof(float) * p * p);          // G^T, W^T, R
-    else b += 3 * up256(sizeof(float) * q * p) + 5 * up256(sizeof(float) * q * q);   // Qb^T, U^T, V^T; W1^T, W2^T, P, xV, D
+    if (n >= p) b += 4 * up256(sizeof(float) * p * p);          // M -> R, its Newton-Schulz twin, G, b G + c G^2
+    else b += 3 * up256(sizeof(float) * q * p) + 5 * up256(sizeof(float) * q * q);   // Qb^T, Z, twin; G, b G + c G^2, P, Ac Qb, D
     return b;
 }
 
@@ -347,14 +381,13 @@ int mecha_rotate(const void *a, const void *b, void *out, int64_t n, int64_t p, 
     MECHA_REQUIRE(a != nullptr && b != nullptr && out != nullptr, "NULL tensor pointer");
     MECHA_REQUIRE(n >= 1 && p >= 1, "rotate needs a non-empty 2-D key (got %lld x %lld)", (long long)n, (long long)p);
     MECHA_REQUIRE(mecha_valid_dtype(in_dtype) && mecha_valid_dtype(out_dtype), "unknown dtype code");
-    MECHA_REQUIRE(p <= JAC_MAX_LEN, "rotate: %lld columns exceed the Jacobi register window (%lld)", (long long)p, (long long)JAC_MAX_LEN);
     const size_t need = rotate_workspace_bytes_impl(n, p);
     MECHA_REQUIRE(workspace != nullptr && workspace_bytes >= need && mecha_aligned16(workspace),
                   "rotate workspace too small or unaligned: need %zu bytes, got %zu", need, workspace_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Bump ws{static_cast<char *>(workspace), 0};
     const int chunks = (int)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
-    unsigned int *counter = ws.take<unsigned int>(64);
+    double *scal = ws.take<double>(8);
     double *part = ws.take<double>((size_t)2 * 64 * p);
     float *a_mean = ws.take<float>(p), *b_mean = ws.take<float>(p);
     float *ac = ws.take<float>(n * p), *bc = ws.take<float>(n * p);
@@ -371,36 +404,33 @@ int mecha_rotate(const void *a, const void *b, void *out, int64_t n, int64_t p, 
     GemmEpilogue fin{};
     fin.col_bias = b_mean; fin.out = out; fin.out_dt = out_dtype; fin.flags = flags;
     int rc;
+    constexpr int MAX_ITERS = 100;
     if (n >= p) {
-        float *gt = ws.take<float>(p * p), *wt = ws.take<float>(p * p), *R = ws.take<float>(p * p);
-        // G^T = M^T:  G^T[j][i] = sum_r Bc[r][j] Ac[r][i]   (row j of G^T = column j of M = Ac^T Bc)
-        gemm(Operand{bc, p, 1}, Operand{ac, p, 1}, gt, p, p, n, slabs, none, s);
-        if ((rc = jacobi_svd(gt, wt, (int)p, p, counter, 30, sweeps_out, s)) != MECHA_OK) return rc;     // M W = U S; gt <- U^T, wt = W^T
-        // R = U W^T:  R[i][j] = sum_k U^T[k][i] W^T[k][j]
-        gemm(Operand{gt, p, 1}, Operand{wt, p, 1}, R, p, p, p, slabs, none, s);
+        float *R = ws.take<float>(p * p), *twin = ws.take<float>(p * p), *G = ws.take<float>(p * p), *G2 = ws.take<float>(p * p);
+        // M = Ac^T Bc:  M[i][j] = sum_r Ac[r][i] Bc[r][j];  R = U V^T = the orthogonal polar factor of M
+        gemm(Operand{ac, p, 1}, Operand{bc, p, 1}, R, p, p, n, slabs, none, s);
+        if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
         // out[r][j] = sum_i Ac[r][i] R[i][j] + b_mean[j]
         gemm(Operand{ac, 1, p}, Operand{R, p, 1}, nullptr, n, p, p, slabs, fin, s);
     } else {
-        float *qbt = ws.take<float>(n * p), *ut = ws.take<float>(n * p), *vt = ws.take<float>(n * p);
-        float *w1 = ws.take<float>(n * n), *w2 = ws.take<float>(n * n), *P = ws.take<float>(n * n), *xv = ws.take<float>(n * n), *D = ws.take<float>(n * n);
-        // orthonormal basis of the row space of Bc: orthogonalise the n rows of Bc (= columns of b.mH)
+        float *qbt = ws.take<float>(n * p), *z = ws.take<float>(n * p), *twin = ws.take<float>(n * p);
+        float *G = ws.take<float>(n * n), *G2 = ws.take<float>(n * n), *P = ws.take<float>(n * n), *aq = ws.take<float>(n * n), *D = ws.take<float>(n * n);
+        // Qb^T = polar factor of Bc: orthonormal rows spanning the row space of Bc (= columns of b.mH)
         MECHA_CHECK_HIP(hipMemcpyAsync(qbt, bc, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-        if ((rc = jacobi_svd(qbt, w1, (int)n, p, counter, 30, sweeps_out, s)) != MECHA_OK) return rc;     // qbt <- Qb^T
+        if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
         // T^T = Bc Qb =: P (n x n):  P[r][k] = sum_c Bc[r][c] Qb^T[k][c]
         gemm(Operand{bc, 1, p}, Operand{qbt, 1, p}, P, n, n, p, slabs, none, s);
-        // N^T = P^T Ac (n vectors of length p):  N^T[k][i] = sum_r P[r][k] Ac[r][i]
-        gemm(Operand{P, n, 1}, Operand{ac, p, 1}, ut, n, p, n, slabs, none, s);
-        if ((rc = jacobi_svd(ut, w2, (int)n, p, counter, 30, sweeps_out, s)) != MECHA_OK) return rc;      // N W2 = U S; ut <- U^T, w2 = W2^T
-        // V^T = W2^T Qb^T:  V^T[k][c] = sum_j W2^T[k][j] Qb^T[j][c]
-        gemm(Operand{w2, 1, n}, Operand{qbt, p, 1}, vt, n, p, n, slabs, none, s);
-        // xV[r][k] = sum_c Ac[r][c] V^T[k][c];  D = xU - xV
-        gemm(Operand{ac, 1, p}, Operand{vt, 1, p}, xv, n, n, p, slabs, none, s);
-        GemmEpilogue minus_xv{};
-        minus_xv.minus = xv;
-        gemm(Operand{ac, 1, p}, Operand{ut, 1, p}, D, n, n, p, slabs, minus_xv, s);
-        // out[r][c] = Ac[r][c] + sum_k D[r][k] V^T[k][c] + b_mean[c]
+        // N^T = P^T Ac (n x p):  N^T[k][i] = sum_r P[r][k] Ac[r][i];  N = U S W^T, Z := polar(N^T) = W U^T
+        gemm(Operand{P, n, 1}, Operand{ac, p, 1}, z, n, p, n, slabs, none, s);
+        if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
+        // with V = Qb W:  U V^T = Z^T Qb^T and V V^T = Qb Qb^T, so  out = Ac + (Ac Z^T - Ac Qb) Qb^T + b_mean
+        gemm(Operand{ac, 1, p}, Operand{qbt, 1, p}, aq, n, n, p, slabs, none, s);              // aq[r][k] = sum_c Ac[r][c] Qb^T[k][c]
+        GemmEpilogue minus_aq{};
+        minus_aq.minus = aq;
+        gemm(Operand{ac, 1, p}, Operand{z, 1, p}, D, n, n, p, slabs, minus_aq, s);             // D = Ac Z^T - Ac Qb
+        // out[r][c] = Ac[r][c] + sum_k D[r][k] Qb^T[k][c] + b_mean[c]
         fin.plus = ac;
-        gemm(Operand{D, 1, n}, Operand{vt, p, 1}, nullptr, n, p, n, slabs, fin, s);
+        gemm(Operand{D, 1, n}, Operand{qbt, p, 1}, nullptr, n, p, n, slabs, fin, s);
     }
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;

@@ -52,7 +52,7 @@ def test_rotate_vs_oracle(oracle, shape, cz):
     got, sweeps = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=cz, return_sweeps=True)
     rel = rotate_rel_error(oracle, a, b, got.cpu().numpy(), want, cz)
     assert rel <= 1e-3, (shape, cz, rel, sweeps)
-    assert 1 <= sweeps <= 60
+    assert 1 <= sweeps <= 200          # Newton-Schulz iterations (two polar solves for wide keys)
     # the transform is orthogonal on the rotated subspace: norms of centred rows are preserved (tall / square keys)
     n, p = oracle.rotate_shape_2d(shape)
     if n >= p and n > p + 1:
