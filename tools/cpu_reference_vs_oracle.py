@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""SURVEY.md §8d "CPU baseline beside it" (i): time the REAL reference (`sd_mecha.merge`, imported from /root/reference)
+and this repo's CPU restatement (the oracle behind the key scheduler, tests/oracle_backend.py) on the same synthetic
+checkpoints, in the build container.  Shows that the restatement `bench.py` times on the GPU box (`cpu_baseline`) is a
+faithful stand-in for the reference's own CPU path.  Never runs on the GPU box (the reference cannot travel).
+
+    python tools/cpu_reference_vs_oracle.py --config 1            # sd1-ldm without ema x2, weighted_sum alpha=0.5, fp16
+    python tools/cpu_reference_vs_oracle.py --config 2 --stride 10  # every 10th sdxl-sgm key x4, TIES k=0.2, bf16
+"""
+import argparse
+import json
+import os
+import pathlib
+import shutil
+import sys
+import time
+import types
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def import_reference():
+    fw = types.ModuleType("fuzzywuzzy")
+    fwp = types.ModuleType("fuzzywuzzy.process")
+    fwp.extractOne = lambda q, choices, **k: (next(iter(choices), None), 0)     # only decorates error messages
+    fw.process = fwp
+    sys.modules["fuzzywuzzy"] = fw
+    sys.modules["fuzzywuzzy.process"] = fwp
+    sys.path.insert(0, "/root/reference")
+    import sd_mecha
+    from sd_mecha.extensions.builtin.merge_methods import linear, ties
+    return sd_mecha, linear, ties
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--stride", type=int, default=1, help="take every n-th key (config 2: 10 = the 10 %% subset of SURVEY §8d)")
+    ap.add_argument("--dir", default="/tmp/mecha_cpu_cmp")
+    args = ap.parse_args()
+    from sd_mecha_amd.shapes import load_manifest, numel
+    from sd_mecha_amd.streaming import OutSafetensorsDict, TensorMetadata
+    import sd_mecha_amd as amd
+    from oracle_backend import OracleBackend
+
+    if args.config == 1:
+        manifest = [(k, s, d) for k, s, d in load_manifest("sd1-ldm") if d.startswith("float") and not k.startswith("model_ema.")]
+        n_models, dtype = 2, torch.float16
+    else:
+        manifest = [(k, s, d) for k, s, d in load_manifest("sdxl-sgm") if d.startswith("float")]
+        n_models, dtype = 4, torch.bfloat16
+    manifest = manifest[::args.stride]
+    work = pathlib.Path(args.dir)
+    work.mkdir(parents=True, exist_ok=True)
+    try:
+        gen = torch.Generator().manual_seed(5)
+        paths = []
+        for m in range(n_models):
+            p = work / f"m{m}.safetensors"
+            sink = OutSafetensorsDict(p, {k: TensorMetadata(tuple(s), dtype) for k, s, _ in manifest}, None)
+            for k, s, _ in manifest:
+                sink[k] = (torch.randn(max(numel(s), 1), generator=gen) * 0.02).to(dtype)[:numel(s)].view(tuple(s))
+            sink.close()
+            paths.append(p)
+        elems = sum(numel(s) for _, s, _ in manifest)
+        moved = elems * 2 * (n_models + 1)
+
+        sd_mecha, linear, ties = import_reference()
+        from tqdm import tqdm
+
+        class quiet(tqdm):
+            def __init__(self, *a, **k):
+                k["disable"] = True
+                super().__init__(*a, **k)
+
+        rm = [sd_mecha.model(p) for p in paths]
+        if args.config == 1:
+            ref_recipe = linear.weighted_sum(rm[0], rm[1], alpha=0.5)
+        else:
+            ref_recipe = linear.add_difference(rm[0], ties.ties_sum(*[linear.subtract(x, rm[0]) for x in rm[1:]], k=0.2), alpha=1.0) | rm[0]
+        out_ref = work / "out_ref.safetensors"
+        t0 = time.perf_counter()
+        sd_mecha.merge(ref_recipe, output=out_ref, merge_device="cpu", output_dtype=dtype, tqdm=quiet)
+        t_ref = time.perf_counter() - t0
+
+        om = [amd.model(str(p)) for p in paths]
+        if args.config == 1:
+            our_recipe = amd.weighted_sum(om[0], om[1], alpha=0.5)
+        else:
+            our_recipe = amd.add_difference(om[0], amd.ties_sum(*[amd.subtract(x, om[0]) for x in om[1:]], k=0.2), alpha=1.0) | om[0]
+        from oracle import oracle as O
+        O.build()
+        O.set_threads(os.cpu_count() or 1)
+        out_our = work / "out_oracle.safetensors"
+        t0 = time.perf_counter()
+        amd.merge(our_recipe, output=str(out_our), merge_device="cpu", output_dtype=dtype, backend=OracleBackend(), total_buffer_size=2 ** 31)
+        t_our = time.perf_counter() - t0
+
+        # same bytes?  (the file layouts differ -- tensor order -- so compare tensor by tensor)
+        from sd_mecha_amd.streaming import InSafetensorsDict
+        a, b = InSafetensorsDict(out_ref), InSafetensorsDict(out_our)
+        keys = sorted(set(a.keys()) & set(b.keys()))
+        differing = 0
+        worst = 0
+        for k in keys:
+            x, y = a[k].view(torch.int16).numpy().astype(np.int32), b[k].view(torch.int16).numpy().astype(np.int32)
+            d = np.abs(x - y)
+            if d.size and d.max() > 0:
+                differing += 1
+                worst = max(worst, int(d.max()))
+        print(json.dumps({
+            "config": args.config, "stride": args.stride, "keys": len(manifest), "elements": elems, "bytes_moved": moved,
+            "reference_seconds": round(t_ref, 2), "reference_GBs": round(moved / t_ref / 1e9, 3),
+            "oracle_scheduler_seconds": round(t_our, 2), "oracle_GBs": round(moved / t_our / 1e9, 3),
+            "torch_threads": torch.get_num_threads(), "cpu_count": os.cpu_count(),
+            "keys_in_both_outputs": len(keys), "keys_in_reference_output": len(list(a.keys())),
+            "keys_with_any_bit_difference": differing, "worst_difference_in_output_ulps": worst,
+        }), flush=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
