@@ -366,6 +366,7 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
         return {
             "h_in": [torch.empty(cap, dtype=in_dtype, **pin) for _ in range(n_models)],
             "h_out": torch.empty(cap, dtype=output_dtype, **pin),
+            "h_flags_pinned": torch.empty(max(len(w.layout.keys) for w in waves), dtype=torch.int32, **pin),
             "d_in": [torch.empty(cap, dtype=in_dtype, device=dev) for _ in range(n_models)],
             "d_out": torch.empty(cap, dtype=output_dtype, device=dev),
             "flags": None, "h_flags": None, "ev_h2d": None, "ev_comp": None, "ev_d2h": None, "wave": None,
@@ -420,9 +421,11 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
         bs["segs_host"] = segs_host
         ctx_in = torch.cuda.stream(s_copy_in) if is_cuda else _null()
         with ctx_in:
+            # the (small, pageable, hence synchronous) segment-table copy goes FIRST: behind the arena copies it would
+            # block the host until ~GBs of H2D have drained
+            segs_dev = L.device_segments(dev)
             for mi in range(n_models):
                 bs["d_in"][mi][:L.total_elems].copy_(bs["h_in"][mi][:L.total_elems], non_blocking=True)
-            segs_dev = L.device_segments(dev)
             if is_cuda:
                 bs["ev_h2d"] = torch.cuda.Event()
                 bs["ev_h2d"].record(s_copy_in)
@@ -443,9 +446,12 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
             if is_cuda:
                 s_copy_out.wait_event(bs["ev_comp"])
             bs["h_out"][:L.total_elems].copy_(bs["d_out"][:L.total_elems], non_blocking=True)
-            bs["h_flags"] = flags.to("cpu", non_blocking=False) if not is_cuda else torch.empty(len(L.keys), dtype=torch.int32, pin_memory=True)
             if is_cuda:
+                bs["h_flags"] = bs["h_flags_pinned"][:len(L.keys)]
                 bs["h_flags"].copy_(flags, non_blocking=True)
+            else:
+                bs["h_flags"] = flags.to("cpu", non_blocking=False)
+            if is_cuda:
                 bs["ev_d2h"] = torch.cuda.Event()
                 bs["ev_d2h"].record(s_copy_out)
 

@@ -1,0 +1,101 @@
+"""Host entry points of libmecha_hip.so (csrc/hostio.cpp): the scheduler's file traffic.  No GPU involved: these run
+wherever the library loads.  They replace the reference's locked read window + clone (streaming.py:151-178) and its
+buffered writer (streaming.py:277-308) for the batched path, so the check is byte equality with plain file I/O."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from sd_mecha_amd import _lib
+
+
+def _arr(values, dtype):
+    return np.ascontiguousarray(values, dtype=dtype)
+
+
+def test_pread_many_scatters_and_zero_fills(tmp_path):
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    blobs = [rng.integers(0, 256, size=n, dtype=np.uint8) for n in (10_000_001, 4096, 123)]      # > 4 MiB: split into pieces
+    fds = []
+    for i, b in enumerate(blobs):
+        p = tmp_path / f"f{i}.bin"
+        p.write_bytes(b.tobytes())
+        fds.append(os.open(p, os.O_RDONLY))
+    try:
+        dst = np.full(12_000_000, 0xAB, dtype=np.uint8)
+        # (fd index, file offset, nbytes, dst offset); fd -1 = zero fill
+        plan = [(0, 0, 10_000_001, 64), (1, 100, 3000, 10_100_000), (2, 3, 120, 11_000_000), (-1, 0, 500, 11_500_000), (1, 0, 0, 5)]
+        fd_a = _arr([fds[i] if i >= 0 else -1 for i, *_ in plan], np.int32)
+        dst_a = _arr([dst.ctypes.data + d for *_, d in plan], np.uint64)
+        size_a = _arr([n for _, _, n, _ in plan], np.uint64)
+        off_a = _arr([o for _, o, _, _ in plan], np.int64)
+        for threads in (1, 5):
+            dst[:] = 0xAB
+            _lib.check(L.mecha_host_pread_many(fd_a.ctypes.data, dst_a.ctypes.data, size_a.ctypes.data, off_a.ctypes.data, len(plan), threads), "pread")
+            assert np.array_equal(dst[64:64 + 10_000_001], blobs[0])
+            assert np.array_equal(dst[10_100_000:10_103_000], blobs[1][100:3100])
+            assert np.array_equal(dst[11_000_000:11_000_120], blobs[2][3:123])
+            assert not dst[11_500_000:11_500_500].any()
+            assert (dst[:64] == 0xAB).all() and (dst[11_500_500:] == 0xAB).all()          # nothing else touched
+        # reading past the end of a file is an error, not a short read
+        bad_size = _arr([200], np.uint64)
+        rc = L.mecha_host_pread_many(_arr([fds[2]], np.int32).ctypes.data, dst_a.ctypes.data, bad_size.ctypes.data, _arr([0], np.int64).ctypes.data, 1, 2)
+        assert rc < 0 and b"pread" in L.mecha_last_error()
+    finally:
+        for fd in fds:
+            os.close(fd)
+
+
+@pytest.mark.parametrize("entry", ["mecha_host_pwrite_many", "mecha_host_mmap_write_many"])
+def test_write_many(tmp_path, entry):
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, size=9_000_000, dtype=np.uint8)
+    path = tmp_path / "out.bin"
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        total = 9_500_000
+        os.ftruncate(fd, total)
+        # (src offset, nbytes, file offset): unaligned offsets, one piece larger than 4 MiB, one empty
+        plan = [(0, 5_000_003, 4097), (5_000_003, 2_999_997, 6_000_001), (8_000_000, 0, 17), (8_000_000, 400_000, 9_000_001), (8_500_000, 4000, 1)]
+        src_a = _arr([src.ctypes.data + s for s, _, _ in plan], np.uint64)
+        size_a = _arr([n for _, n, _ in plan], np.uint64)
+        off_a = _arr([o for _, _, o in plan], np.int64)
+        _lib.check(getattr(L, entry)(fd, src_a.ctypes.data, size_a.ctypes.data, off_a.ctypes.data, len(plan), 4), entry)
+        got = np.frombuffer(path.read_bytes(), dtype=np.uint8)
+        assert got.size == total
+        want = np.zeros(total, dtype=np.uint8)
+        for s, n, o in plan:
+            want[o:o + n] = src[s:s + n]
+        assert np.array_equal(got, want)
+        if entry == "mecha_host_mmap_write_many":
+            # the mapping variant refuses to write past the end of the file instead of faulting
+            far = _arr([total - 10], np.int64)
+            rc = getattr(L, entry)(fd, src_a.ctypes.data, _arr([100], np.uint64).ctypes.data, far.ctypes.data, 1, 1)
+            assert rc < 0 and b"ftruncate" in L.mecha_last_error()
+    finally:
+        os.close(fd)
+
+
+def test_writer_put_many_matches_put(tmp_path):
+    """OutSafetensorsDict.put_many (native team, preallocated file) writes the same file contents as per-key put()."""
+    import torch
+    from sd_mecha_amd.streaming import InSafetensorsDict, OutSafetensorsDict, TensorMetadata
+    rng = np.random.default_rng(2)
+    tensors = {f"k{i}": torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(torch.bfloat16) for i, n in enumerate((5, 70_001, 0, 1 << 21))}
+    header = {k: TensorMetadata(t.shape, t.dtype) for k, t in tensors.items()}
+    a = OutSafetensorsDict(tmp_path / "a.safetensors", header, "recipe")
+    for k, t in tensors.items():
+        a[k] = t
+    a.close()
+    b = OutSafetensorsDict(tmp_path / "b.safetensors", header, "recipe")
+    keys = list(tensors)
+    b.put_many(keys, [header[k] for k in keys], [tensors[k].data_ptr() for k in keys], threads=3)
+    b.close()
+    ra, rb = InSafetensorsDict(tmp_path / "a.safetensors"), InSafetensorsDict(tmp_path / "b.safetensors")
+    assert os.path.getsize(tmp_path / "a.safetensors") == os.path.getsize(tmp_path / "b.safetensors")
+    assert ra.file_metadata() == rb.file_metadata() == {"mecha_recipe": "recipe"}
+    for k, t in tensors.items():
+        assert torch.equal(ra[k], t) and torch.equal(rb[k], t)
