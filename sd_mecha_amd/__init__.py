@@ -44,6 +44,7 @@ rotate = merge_method(_mm.rotate)
 lora_merge = merge_method(_mm.lora_merge)
 lora_delta = merge_method(_mm.lora_delta)
 
+from .lora import convert  # noqa: E402,F401   convert(model(lora_file), base): the reference's sd_mecha.convert for kohya LoRAs
 from .merging import merge  # noqa: E402,F401
 
 __version__ = "0.1.0"

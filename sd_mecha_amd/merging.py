@@ -34,6 +34,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import lora as lora_mod
 from . import merge_methods as mm
 from .arena import ArenaLayout, plan_arena, shard_keys_lpt
 from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError
@@ -75,6 +76,10 @@ def _bound(node: MergeRecipeNode) -> Dict[str, RecipeNode]:
 
 def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
     """Recognise the node chains of SURVEY.md §3.2-3.3 (wrappers.py shapes); None = evaluate generically."""
+    chain = lora_mod.parse_chain(recipe)
+    if chain is not None:                                                     # SURVEY.md §3.4: base + sum of LoRA deltas
+        expr, base, loras = chain
+        return FusedPlan("lora", [base], {"expr": expr, "loras": loras})
     fallback = None
     if isinstance(recipe, MergeRecipeNode) and recipe.merge_method.identifier == "fallback":
         a, d = recipe.args[0], recipe.args[1] if len(recipe.args) > 1 else recipe.kwargs.get("default")
@@ -139,6 +144,90 @@ def collect_models(recipe: RecipeNode) -> List[ModelRecipeNode]:
     return out
 
 
+def _lora_file_nodes(recipe: RecipeNode) -> set:
+    """ids of the model nodes that only appear as the LoRA-file argument of convert(lora, base)."""
+    as_lora, other = set(), set()
+
+    def walk(n, is_lora_arg=False):
+        if isinstance(n, ModelRecipeNode):
+            (as_lora if is_lora_arg else other).add(id(n))
+        elif isinstance(n, MergeRecipeNode):
+            conv = n.merge_method.identifier == "convert_lora_to_base"
+            for i, a in enumerate(n.args):
+                walk(a, conv and i == 0)
+            for a in n.kwargs.values():
+                walk(a)
+    walk(recipe)
+    return as_lora - other
+
+
+class _LoraStore:
+    """The factors of every LoRA file of a fused LoRA plan, resident on the compute device: one pread scatter list per file
+    into a (pinned) staging buffer at 16-byte aligned offsets, one H2D copy, tensors as views.  Alpha scalars stay on the
+    host (they turn into the fp32 scale alpha / rank, lycoris.py:263)."""
+
+    def __init__(self, plan: FusedPlan, readers, device: torch.device, host_threads: int):
+        self.expr = plan.params["expr"]
+        self.files = []
+        for node in plan.params["loras"]:
+            reader = readers[id(node)]
+            names = [k for k, m in reader.metadata() if k.endswith(lora_mod.UP) or k.endswith(lora_mod.DOWN)]
+            offs, total = {}, 0
+            for k in names:
+                offs[k] = total
+                total += (reader.meta(k).nbytes() + 15) // 16 * 16
+            pin = dict(pin_memory=True) if device.type == "cuda" else {}
+            host = torch.empty(max(total, 16), dtype=torch.uint8, **pin)
+            if names:
+                fds = np.full(len(names), reader.fileno(), dtype=np.int32)
+                dst = np.asarray([host.data_ptr() + offs[k] for k in names], dtype=np.uint64)
+                size = np.asarray([reader.meta(k).nbytes() for k in names], dtype=np.uint64)
+                foff = np.asarray([reader.file_offset(k) for k in names], dtype=np.int64)
+                _lib.check(_lib.lib().mecha_host_pread_many(fds.ctypes.data, dst.ctypes.data, size.ctypes.data, foff.ctypes.data,
+                                                            len(names), host_threads), "mecha_host_pread_many")
+            dev_buf = host.to(device) if device.type == "cuda" else host
+            self.files.append((reader, dev_buf, offs))
+
+    def _tensor(self, f: int, name: str) -> torch.Tensor:
+        reader, buf, offs = self.files[f]
+        m = reader.meta(name)
+        return buf[offs[name]:offs[name] + m.nbytes()].view(m.dtype).view(tuple(m.shape))
+
+    def entries(self, layout: ArenaLayout, header) -> Tuple[list, set]:
+        """([(index in the wave, offset, rows, cols, [(up, down, alpha, weight), ...])] for the keys of a wave that are merged,
+        {skipped keys})."""
+        out, skip = [], set()
+        for index, (key, off, n) in enumerate(zip(layout.keys, layout.offsets, layout.numels)):
+            shape = tuple(header[key].shape)
+            prefix = lora_mod.lora_key_prefix(key, shape)
+            found = {}
+
+            def has(i, prefix=prefix, found=found):
+                if prefix is None:
+                    return False
+                if i not in found:
+                    try:
+                        found[i] = lora_mod.network_entries(self.files[i][0], prefix)
+                    except StateDictKeyError:
+                        found[i] = None
+                return found[i] is not None
+            try:
+                applied = lora_mod.networks_for_key(self.expr, has)
+            except StateDictKeyError:
+                skip.add(key)
+                continue
+            rows = shape[0] if len(shape) >= 2 else 1
+            cols = n // rows if rows else 0
+            nets = []
+            for i, alpha_w in applied:
+                up_k, down_k, alpha_k = found[i]
+                alpha = self.files[i][0][alpha_k] if alpha_k is not None else None
+                nets.append((self._tensor(i, up_k), self._tensor(i, down_k), alpha, alpha_w))
+            if n:
+                out.append((index, off, rows, cols, nets))
+        return out, skip
+
+
 # ================================================================== compute backends
 class HipBackend:
     """libmecha_hip.so on the current ROCm device.  The only product backend: no CPU path."""
@@ -175,6 +264,15 @@ class HipBackend:
         else:
             raise ValueError(plan.kind)
         _lib.check(st, f"batched {plan.kind}")
+
+    def run_lora(self, entries, base: torch.Tensor, out: torch.Tensor, flags: torch.Tensor) -> None:
+        """Every key of a wave in one launch; `entries` as _LoraStore.entries returns them, `flags` one word per wave key."""
+        if not entries:
+            return
+        batch = mm.LoraBatch([(off, rows, cols, nets) for _, off, rows, cols, nets in entries], self.device)
+        entry_flags = torch.zeros(len(entries), dtype=torch.int32, device=self.device)
+        batch.run(base, out, entry_flags)
+        flags.index_copy_(0, torch.tensor([i for i, *_ in entries], dtype=torch.int64, device=self.device), entry_flags)
 
     def workspace_bytes(self, plan: FusedPlan, layout: ArenaLayout) -> int:
         if plan.kind == "ties":
@@ -265,8 +363,12 @@ def merge(
         plan = fuse(recipe)
         recipe_text = serialize(recipe)
         # structural key inference: keys every input of the merge holds with one shape (minimal)
-        first = readers[id(models[0])]
-        merge_inputs = plan.models if plan is not None else models
+        # LoRA files name their tensors after the base keys (lora_<stem>.lora_up.weight ...): they take no part in key inference
+        aux = _lora_file_nodes(recipe)
+        merge_inputs = plan.models if plan is not None else [m for m in models if id(m) not in aux]
+        if not merge_inputs:
+            raise ValueError("the recipe has no model inputs besides LoRA files")
+        first = readers[id(merge_inputs[0])]
         items, header = [], {}
         for key, meta in first.metadata():
             ok = all(key in readers[id(m)] and readers[id(m)].meta(key).shape == meta.shape for m in merge_inputs)
@@ -380,6 +482,7 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
 
     host_threads = max(1, min(int(os.environ.get("MECHA_HOST_THREADS", "16")), os.cpu_count() or 1))
     writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+    lora_store = _LoraStore(plan, readers, dev, host_threads) if plan.kind == "lora" else None
     hostlib = _lib.lib()
 
     def stage(bs, wave: _Wave):
@@ -436,7 +539,12 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
             flags = torch.zeros(len(L.keys), dtype=torch.int32, device=dev)
             nbytes = backend.workspace_bytes(plan, L)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if nbytes else None
-            backend.run_fused(plan, [a[:L.total_elems] for a in bs["d_in"]], bs["d_out"][:L.total_elems], L, segs_dev, segs_host, flags, ws)
+            if plan.kind == "lora":
+                entries, bs["skip"] = lora_store.entries(L, header)
+                backend.run_lora(entries, bs["d_in"][0][:L.total_elems], bs["d_out"][:L.total_elems], flags)
+            else:
+                bs["skip"] = ()
+                backend.run_fused(plan, [a[:L.total_elems] for a in bs["d_in"]], bs["d_out"][:L.total_elems], L, segs_dev, segs_host, flags, ws)
             bs["flags"], bs["ws"], bs["segs_dev"] = flags, ws, segs_dev
             if is_cuda:
                 bs["ev_comp"] = torch.cuda.Event()
@@ -469,6 +577,9 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
         put_keys, put_metas, put_ptrs = [], [], []
         for i, (key, off, n) in enumerate(zip(L.keys, L.offsets, L.numels)):
             meta = header[key]
+            if key in bs["skip"]:                                            # no LoRA entry and no fallback: the key is omitted
+                skipped.append(key)
+                continue
             if fl[i] & _lib.FLAG_INPUT_NONFINITE:
                 if not _write_fallback(plan, readers, key, meta, sink, to_file, output_device, output_dtype):
                     skipped.append(key)
@@ -569,6 +680,15 @@ def _run_generic(recipe, backend, readers, items, header, sink, to_file, output_
                     except StateDictKeyError:
                         continue
                 raise StateDictKeyError(key)
+            if node.merge_method.identifier == "convert_lora_to_base":        # LycorisToBase.__call__ (lycoris.py:69-85)
+                lora_node, base_node = node.args
+                reader, meta = readers[id(lora_node)], readers[id(base_node)].meta(key)
+                prefix = lora_mod.lora_key_prefix(key, tuple(meta.shape), meta.dtype.is_floating_point)
+                if prefix is None:
+                    raise StateDictKeyError(key)
+                up_k, down_k, alpha_k = lora_mod.network_entries(reader, prefix)
+                alpha = reader[alpha_k] if alpha_k is not None else None
+                return methods.lora_delta(reader[up_k].to(dev), reader[down_k].to(dev), alpha, tuple(meta.shape))
             args = [evaluate(a, key) for a in node.args]
             kwargs = {k: evaluate(v, key) for k, v in node.kwargs.items()}
             return node.merge_method.merge_key(args, kwargs, key)

@@ -255,10 +255,72 @@ def gen_e2e(out):
     out["shapes_keys"] = np.array(list(shapes.keys()))
 
 
+def gen_e2e_lora(out):
+    """sd_mecha.convert(model(lora_file), base) + add_difference through sd_mecha.merge (lycoris.py:52-85) on a
+    toy checkpoint with REAL sdxl-kohya key names and shapes (LycorisToBase takes the target shape from the config).
+    The wrapper sd_mecha.add_difference raises on merge-node inputs in this revision, so the recipes are
+    built from the registered primitive and explicit `|` fallbacks."""
+    import safetensors.torch
+    from tqdm import tqdm
+
+    class quiet(tqdm):
+        def __init__(self, *a, **k):
+            k["disable"] = True
+            super().__init__(*a, **k)
+
+    g = torch.Generator().manual_seed(31)
+    shapes = {"unet.input_blocks.0.0.weight": (320, 4, 3, 3), "unet.out.2.weight": (4, 320, 3, 3),
+              "te1.text_model.embeddings.position_embedding.weight": (77, 768), "unet.out.2.bias": (4,), "unet.input_blocks.0.0.bias": (320,)}
+    base = {k: (torch.randn(s, generator=g) * 0.02).to(torch.bfloat16) for k, s in shapes.items()}
+
+    def lora_for(keys, rank, with_alpha):
+        sd = {}
+        for k in keys:
+            s = shapes[k]
+            stem = "lora_" + "_".join(k.split(".")[:-1])
+            sd[stem + ".lora_up.weight"] = (torch.randn(s[0], rank, generator=g) * 0.05).half()
+            sd[stem + ".lora_down.weight"] = (torch.randn((rank,) + tuple(s[1:]), generator=g) * 0.05).half()
+            if with_alpha:
+                sd[stem + ".alpha"] = torch.tensor(rank / 2).half()
+        return sd
+
+    two_d = [k for k, s in shapes.items() if len(s) >= 2]
+    loras = [lora_for(two_d, 8, True), lora_for(two_d[:2], 4, False)]        # the second file has no entry for the te1 key
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        safetensors.torch.save_file(base, str(td / "base.safetensors"))
+        for i, sd in enumerate(loras):
+            safetensors.torch.save_file(sd, str(td / f"l{i}.safetensors"))
+        for k, t in base.items():
+            out[f"base_{k}"] = bits(t)
+        for i, sd in enumerate(loras):
+            out[f"l{i}_keys"] = np.array(sorted(sd.keys()))
+            for k, t in sd.items():
+                out[f"l{i}_{k}"] = bits(t)
+        b = sd_mecha.model(td / "base.safetensors", config="sdxl-kohya")
+        d = [sd_mecha.convert(sd_mecha.model(td / f"l{i}.safetensors"), b) for i in range(2)]
+        kw = dict(threads=0, output_dtype=torch.bfloat16, tqdm=quiet)
+        x1 = linear.add_difference(b, d[0], alpha=0.75) | b
+        recipes = {
+            "chain": linear.add_difference(x1, d[1], alpha=1.0) | x1,            # a missing network keeps the previous value
+            "outer_base": linear.add_difference(x1, d[1], alpha=1.0) | b,       # ... or falls all the way back to the base
+            "strict": linear.add_difference(linear.add_difference(b, d[0], alpha=0.75), d[1], alpha=0.5),   # no fallback: keys are omitted
+        }
+        for name, r in recipes.items():
+            res = {k: v for k, v in sd_mecha.merge(r, **kw).items() if k != "__metadata__"}
+            out[f"{name}_keys"] = np.array(sorted(res.keys()))
+            for k, v in res.items():
+                out[f"{name}_{k}"] = bits(v)
+    out["shapes_keys"] = np.array(list(shapes.keys()))
+
+
 def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
+    only = set(sys.argv[1:])
     for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare),
-                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e)]:
+                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_lora", gen_e2e_lora)]:
+        if only and name not in only:
+            continue
         out = {}
         fn(out)
         np.savez_compressed(HERE / f"{name}.npz", **out)

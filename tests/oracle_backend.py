@@ -46,3 +46,24 @@ class OracleBackend:
             if not O.all_finite(res):
                 fl[i] |= 2
             o_bits[off:off + n] = O.from_f32(res, out_name) if out_name != "float32" else res
+
+    def run_lora(self, entries, base, out, flags):
+        """base + sum of LoRA deltas per key (lycoris.py:226-263 + linear.py:64-76) with the oracle's arithmetic."""
+        in_name, out_name = _NAME[base.dtype], _NAME[out.dtype]
+        b_bits, o_bits, fl = _bits(base), _bits(out), flags.numpy()
+        for index, off, rows, cols, nets in entries:
+            n = rows * cols
+            acc = O.to_f32(b_bits[off:off + n], in_name).reshape(rows, cols)
+            ok = O.all_finite(acc)
+            for up, down, alpha, weight in nets:
+                up32 = O.to_f32(_bits(up.reshape(up.shape[0], -1)), _NAME[up.dtype]).reshape(up.shape[0], -1)
+                down32 = O.to_f32(_bits(down.reshape(down.shape[0], -1)), _NAME[down.dtype]).reshape(down.shape[0], -1)
+                ok = ok and O.all_finite(up32) and O.all_finite(down32)
+                a = None if alpha is None else float(torch.as_tensor(alpha).float())
+                acc = O.add_difference(acc, O.lora_delta(up32, down32, a), weight)
+            if not ok:
+                fl[index] |= 1
+                continue
+            if not O.all_finite(acc):
+                fl[index] |= 2
+            o_bits[off:off + n] = O.from_f32(acc, out_name).reshape(-1) if out_name != "float32" else acc.reshape(-1)
