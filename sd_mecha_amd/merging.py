@@ -136,6 +136,9 @@ def collect_models(recipe: RecipeNode) -> List[ModelRecipeNode]:
                 seen.add(id(n))
                 out.append(n)
         elif isinstance(n, MergeRecipeNode):
+            if id(n) in seen:                                                   # recipes are DAGs: visit shared nodes once
+                return
+            seen.add(id(n))
             for a in n.args:
                 walk(a)
             for a in n.kwargs.values():
@@ -146,12 +149,15 @@ def collect_models(recipe: RecipeNode) -> List[ModelRecipeNode]:
 
 def _lora_file_nodes(recipe: RecipeNode) -> set:
     """ids of the model nodes that only appear as the LoRA-file argument of convert(lora, base)."""
-    as_lora, other = set(), set()
+    as_lora, other, visited = set(), set(), set()
 
     def walk(n, is_lora_arg=False):
         if isinstance(n, ModelRecipeNode):
             (as_lora if is_lora_arg else other).add(id(n))
         elif isinstance(n, MergeRecipeNode):
+            if id(n) in visited:
+                return
+            visited.add(id(n))
             conv = n.merge_method.identifier == "convert_lora_to_base"
             for i, a in enumerate(n.args):
                 walk(a, conv and i == 0)

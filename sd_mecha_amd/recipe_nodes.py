@@ -166,14 +166,18 @@ def serialize(recipe: RecipeNode) -> str:
             return node(v)
         raise TypeError(f"type {type(v)} cannot be serialized: {v}")
 
+    done: Dict[int, str] = {}                   # recipes are DAGs (`x | x`-style sharing): each node is visited once
+
     def node(n: RecipeNode) -> str:
         if isinstance(n, ModelRecipeNode):
             return add(f"model {value(str(n.path))} model_config=null merge_space=\"weight\"")
         if isinstance(n, LiteralRecipeNode):
             return value(n.value)
         if isinstance(n, MergeRecipeNode):
-            parts = ["merge", value(n.merge_method.identifier)] + [value(a) for a in n.args] + [f"{k}={value(v)}" for k, v in n.kwargs.items()]
-            return add(" ".join(parts))
+            if id(n) not in done:
+                parts = ["merge", value(n.merge_method.identifier)] + [value(a) for a in n.args] + [f"{k}={value(v)}" for k, v in n.kwargs.items()]
+                done[id(n)] = add(" ".join(parts))
+            return done[id(n)]
         raise TypeError(type(n))
 
     node(recipe)

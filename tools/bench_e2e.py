@@ -30,7 +30,29 @@ WORKLOADS = {
     "sdxl_navg": ("sdxl-sgm", None, 4, "navg"),
     "sdxl_wsum": ("sdxl-sgm", None, 2, "wsum"),
     "sd1_wsum": ("sd1-ldm", None, 2, "wsum"),
+    # BASELINE config 5: one base (kohya key naming) + 16 kohya LoRA files, rank 32, fp16, alpha 16, weight 1.0
+    "sdxl_lora": ("sdxl-kohya", None, 1, "lora"),
 }
+N_LORAS, LORA_RANK = 16, 32
+
+
+def write_lora(path, manifest, seed, device):
+    from sd_mecha_amd.lora import lora_key_prefix
+    gen = torch.Generator(device=device).manual_seed(seed)
+    tensors = {}
+    for k, s, _ in manifest:
+        prefix = lora_key_prefix(k, s)
+        if prefix is None:
+            continue
+        rows, cols = s[0], numel(s) // s[0]
+        tensors[f"{prefix}.lora_up.weight"] = torch.empty((rows, LORA_RANK), dtype=torch.float16, device=device).normal_(0.0, 0.02, generator=gen).cpu()
+        tensors[f"{prefix}.lora_down.weight"] = torch.empty((LORA_RANK,) + tuple(s[1:]), dtype=torch.float16, device=device).normal_(0.0, 0.02, generator=gen).cpu()
+        tensors[f"{prefix}.alpha"] = torch.tensor(16.0, dtype=torch.float16)
+    sink = OutSafetensorsDict(path, {k: TensorMetadata(tuple(t.shape), t.dtype) for k, t in tensors.items()}, None)
+    for k, t in tensors.items():
+        sink[k] = t
+    sink.close()
+    return sum(t.numel() * 2 for t in tensors.values())
 
 
 def write_checkpoint(path, manifest, seed, device):
@@ -77,9 +99,20 @@ def main():
             p = work / f"m{m}.safetensors"
             write_checkpoint(p, manifest, 100 + m, device)
             paths.append(p)
+        lora_bytes = 0
+        if recipe_kind == "lora":
+            lora_paths = []
+            for i in range(N_LORAS):
+                p = work / f"lora{i}.safetensors"
+                lora_bytes += write_lora(p, manifest, 500 + i, device)
+                lora_paths.append(p)
         gen_s = time.perf_counter() - t0
         models = [amd.model(str(p)) for p in paths]
-        if recipe_kind == "ties":
+        if recipe_kind == "lora":
+            recipe = models[0]
+            for p in lora_paths:
+                recipe = amd.add_difference(recipe, amd.convert(amd.model(str(p)), models[0]), alpha=1.0) | recipe
+        elif recipe_kind == "ties":
             deltas = [amd.subtract(m, models[0]) for m in models[1:]]
             recipe = amd.add_difference(models[0], amd.ties_sum(*deltas, k=0.2), alpha=1.0) | models[0]
         elif recipe_kind == "navg":
@@ -87,7 +120,7 @@ def main():
         else:
             recipe = amd.weighted_sum(models[0], models[1], alpha=0.5)
         elems = sum(numel(s) for _, s, _ in manifest)
-        moved = elems * 2 * (n_models + 1)
+        moved = elems * 2 * (n_models + 1) + lora_bytes
         times = []
         for r in range(args.reps):
             out = work / "out.safetensors"
