@@ -166,6 +166,20 @@ int mecha_ties_sum_with_dropout(const void *const *deltas, int n_models, const u
                                 int vote_sgn, float probability, int rescale, float *thresholds_out,
                                 void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream);
 
+/* ties_sum_extended (ties.py:68-94) with apply_median == False, optionally behind the DARE masks of
+ * ties_sum_with_dropout (ties.py:10-50; keep_bits == NULL: no dropout, probability / rescale ignored).
+ * model_stock != 0 applies the Model-Stock factor of ties.py:146-159 -- what the reference does for
+ * apply_stock == False, its default (ties.py:90): per slice of the key's last dimension (`row_len`
+ * elements; numel for 1-D keys) t = n c / (1 + (n - 1) c), c = mean cosine of consecutive filtered deltas
+ * (CosineSimilarity(dim=-1, eps=cos_eps)); out = nan_to_num(sum * t / count) [/ (1 - probability)].
+ * 2..8 deltas with the factor.  model_stock == 0 is mecha_ties_sum / mecha_ties_sum_with_dropout. */
+size_t mecha_ties_extended_workspace_bytes(int n_models, int64_t numel, int64_t row_len);
+int mecha_ties_sum_extended(const void *const *deltas, int n_models, const uint32_t *keep_bits, void *out,
+                            int64_t numel, int64_t row_len, int in_dtype, int out_dtype, double k,
+                            int vote_sgn, int model_stock, float cos_eps, float probability, int rescale,
+                            float *thresholds_out, void *workspace, size_t workspace_bytes,
+                            uint32_t *flags, void *stream);
+
 /* HOST function: the Bernoulli keep masks the reference draws on CPU (ties.py:29-33, :63-64):
  * torch.Generator().manual_seed(seed), then torch.bernoulli(1 - probability) per delta in order
  * (MT19937, one 24-bit uniform per element).  Writes bit-packed masks, layout as `keep_bits`

@@ -35,6 +35,7 @@ slerp = merge_method(_mm.slerp)
 perpendicular_component = merge_method(_mm.perpendicular_component)
 add_perpendicular = merge_method(_mm.add_perpendicular)
 ties_sum = merge_method(_mm.ties_sum)
+ties_sum_extended = merge_method(_mm.ties_sum_extended)
 ties_sum_with_dropout = merge_method(_mm.ties_sum_with_dropout)
 add_difference_ties = merge_method(_mm.add_difference_ties)
 cast = merge_method(_mm.cast)

@@ -949,6 +949,153 @@ __global__ __launch_bounds__(1024) void ties_tile_index_kernel(const mecha_segme
     for (int i = lo; i < hi; i++) { tile_start[i] = run; run += (segs[i].numel + TIES_TILE - 1) / TIES_TILE; }
 }
 
+// ------------------------------------------------------------------------------------------------ model-stock factor
+// ties_sum_extended with apply_stock == False (ties.py:90 -- the flag is inverted upstream: False APPLIES the factor):
+//   t = n c / (1 + (n - 1) c),  c = mean over consecutive pairs of cos(g_i, g_{i+1}) along the LAST dimension
+//   (ties.py:146-159, torch.nn.CosineSimilarity(dim=-1, eps)), g_i = the filtered deltas that agree with the elected sign;
+//   out = nan_to_num(sum_i g_i * t / count).
+// Per-key, delta form, 2..8 deltas.  Three kernels after the thresholds are known: row sums (dot products and squared
+// norms, fp64: torch's fp32 reduction order is not fixed), the factor per row, the apply pass.
+struct StockParams {
+    int64_t row_len, n_rows;
+    double *sums;               // [n_rows][2 n - 1]: n squared norms, then n - 1 dot products
+    float *t;                   // [n_rows]
+    float cos_eps;
+};
+constexpr int STOCK_MAX = 8;
+
+// g[d][j] for the 8 elements at e (filtered by threshold, DARE mask, and agreement with the elected sign) and the agree count
+template <bool DARE>
+__device__ __forceinline__ void stock_agreeing(const TiesParams &p, int vote_sgn, int64_t e, int valid, bool vec, float (&g)[STOCK_MAX][8],
+                                               float (&cnt)[8], bool &bad_in) {
+    float vote[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { vote[j] = 0.0f; cnt[j] = 0.0f; }
+#pragma unroll
+    for (int d = 0; d < STOCK_MAX; d++) {
+        if (d < p.n_deltas) {
+            load_rt(p.in_dt, vec, p.in[d], e, valid, g[d]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(g[d][j]);
+            if constexpr (DARE) apply_keep_bits(p, d, e, g[d]);
+            const float thr = __uint_as_float(p.state[d].threshold_bits);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                g[d][j] = g[d][j] * ((__builtin_fabsf(g[d][j]) >= thr) ? 1.0f : 0.0f);          // filter_top_k (ties.py:128-132)
+                vote[j] += vote_sgn ? g[d][j] : sign_f(g[d][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < STOCK_MAX; d++) {
+        if (d < p.n_deltas) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float agree = (sign_f(g[d][j]) == sign_f(vote[j])) ? 1.0f : 0.0f;          // ties.py:122
+                g[d][j] = g[d][j] * agree;
+                cnt[j] += agree;
+            }
+        }
+    }
+}
+
+template <bool DARE>
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_reduce_kernel(TiesParams p, StockParams sp, int vote_sgn, uint32_t *flags) {
+    const int64_t numel = p.seg0.numel;
+    const int n = p.n_deltas, width = 2 * n - 1;
+    bool bad_in = false;
+    for (int64_t e = ((int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x) * 8; e < numel; e += (int64_t)gridDim.x * MECHA_BLOCK * 8) {
+        const int valid = (numel - e >= 8) ? 8 : (int)(numel - e);
+        float g[STOCK_MAX][8], cnt[8];
+        stock_agreeing<DARE>(p, vote_sgn, e, valid, p.vec_ok && valid == 8, g, cnt, bad_in);
+        double acc[2 * STOCK_MAX - 1];
+        int64_t row = e / sp.row_len;
+        int64_t row_end = (row + 1) * sp.row_len;
+        auto clear = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2 * STOCK_MAX - 1; i++) acc[i] = 0.0;
+        };
+        auto flush = [&](int64_t r) {
+#pragma unroll
+            for (int i = 0; i < 2 * STOCK_MAX - 1; i++)
+                if (i < width && acc[i] != 0.0) atomicAdd(&sp.sums[r * width + i], acc[i]);
+        };
+        clear();
+        // whole wave inside one row (rows of >= 512 elements, mostly): reduce across lanes first, one lane adds
+        const int64_t first_row = __shfl(row, 0, 64);
+        const bool lane_one_row = (e + valid <= row_end);
+        const bool uniform = __ballot(lane_one_row && row == first_row) == ~0ull;        // all 64 lanes active and in one row
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < valid) {
+                if (e + j >= row_end) { flush(row); clear(); row += 1; row_end += sp.row_len; if (e + j >= row_end) { row = (e + j) / sp.row_len; row_end = (row + 1) * sp.row_len; } }
+#pragma unroll
+                for (int d = 0; d < STOCK_MAX; d++) {
+                    if (d < n) {
+                        acc[d] += (double)g[d][j] * (double)g[d][j];
+                        if (d + 1 < n) acc[n + d] += (double)g[d][j] * (double)g[d + 1][j];
+                    }
+                }
+            }
+        }
+        if (uniform) {
+#pragma unroll
+            for (int i = 0; i < 2 * STOCK_MAX - 1; i++) {
+                if (i < width) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+                }
+            }
+            if ((threadIdx.x & 63) == 0) flush(row);
+        } else {
+            flush(row);
+        }
+    }
+    if (bad_in && flags != nullptr) atomicOr(flags, MECHA_FLAG_INPUT_NONFINITE);
+}
+
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_t_kernel(StockParams sp, int n) {
+    const int64_t r = (int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x;
+    if (r >= sp.n_rows) return;
+    const double *s = sp.sums + r * (2 * n - 1);
+    double mean = 0.0;
+    for (int i = 0; i + 1 < n; i++) {
+        // cosine_similarity: x.y / (max(|x|, eps) max(|y|, eps))
+        const double nx = fmax(sqrt(s[i]), (double)sp.cos_eps), ny = fmax(sqrt(s[i + 1]), (double)sp.cos_eps);
+        mean += s[n + i] / (nx * ny);
+    }
+    const float c = (float)(mean / (double)(n - 1));
+    sp.t[r] = ((float)n * c) / (1.0f + (float)(n - 1) * c);                                  // ties.py:158
+}
+
+template <bool DARE>
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_apply_kernel(TiesParams p, StockParams sp, MergeExtra x, void *out, uint32_t *flags) {
+    const int64_t numel = p.seg0.numel;
+    bool bad_in = false, bad_out = false;
+    for (int64_t e = ((int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x) * 8; e < numel; e += (int64_t)gridDim.x * MECHA_BLOCK * 8) {
+        const int valid = (numel - e >= 8) ? 8 : (int)(numel - e);
+        const bool vec = p.vec_ok && valid == 8;
+        float g[STOCK_MAX][8], cnt[8], r[8];
+        stock_agreeing<DARE>(p, x.vote_sgn, e, valid, vec, g, cnt, bad_in);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < STOCK_MAX; d++)
+                if (d < p.n_deltas) acc += g[d][j];                                              // filtered_delta.sum(dim=0)
+            const float t = (j < valid) ? sp.t[(e + j) / sp.row_len] : 0.0f;
+            float q = (acc * t) / cnt[j];                                                        // ties.py:92
+            if (nonfinite_f32(q)) q = 0.0f;                                                      // nan_to_num
+            if (x.has_rescale) q = q / x.rescale_div;                                            // ties.py:50
+            bad_out |= (j < valid) && nonfinite_f32(q);
+            r[j] = q;
+        }
+        store_rt(p.out_dt, vec, out, e, valid, r);
+    }
+    if ((bad_in | bad_out) && flags != nullptr)
+        atomicOr(flags, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+}
+
 // ------------------------------------------------------------------------------------------------ host
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -977,6 +1124,10 @@ WorkspaceLayout layout(int n_deltas, int n_segs, int64_t total_elems) {
     return w;
 }
 
+size_t stock_bytes(int n_deltas, int64_t n_rows) {
+    return align_up(sizeof(double) * (size_t)n_rows * (2 * n_deltas - 1), 256) + align_up(sizeof(float) * (size_t)n_rows, 256);
+}
+
 struct TiesCall {
     const void *base;
     const void *const *inputs;
@@ -994,6 +1145,9 @@ struct TiesCall {
     int vote_sgn;
     float probability;
     int rescale;
+    int model_stock;                        // ties_sum_extended: apply the model-stock factor (per-key delta form only)
+    float cos_eps;
+    int64_t row_len;                        // size of the key's last dimension
     float *thresholds_out;
     void *workspace;
     size_t workspace_bytes;
@@ -1081,8 +1235,18 @@ int run_ties(const TiesCall &c) {
     MECHA_REQUIRE(!(c.base != nullptr && mecha_isclose(c.alpha, 0.0)),
                   "alpha == 0: add_difference returns `a` untouched (linear.py:72-73); call the cast entry point on base instead");
     const WorkspaceLayout w = layout(c.n_deltas, n_segs, batched ? c.total_elems : c.numel);
-    MECHA_REQUIRE(c.workspace != nullptr && c.workspace_bytes >= w.total && mecha_aligned16(c.workspace),
-                  "TIES workspace too small or unaligned: need %zu bytes, got %zu", w.total, c.workspace_bytes);
+    size_t need = w.total;
+    int64_t n_rows = 0;
+    if (c.model_stock) {
+        MECHA_REQUIRE(!batched && c.base == nullptr, "the model-stock factor is supported on the per-key delta form only");
+        MECHA_REQUIRE(c.n_deltas >= 2 && c.n_deltas <= STOCK_MAX, "the model-stock factor needs 2..%d deltas (got %d): the reference's "
+                      "torch.stack of an empty list of cosines raises for one delta", STOCK_MAX, c.n_deltas);
+        MECHA_REQUIRE(c.row_len >= 1 && c.numel % c.row_len == 0, "row_len (%lld) must divide numel (%lld)", (long long)c.row_len, (long long)c.numel);
+        n_rows = c.numel / c.row_len;
+        need += stock_bytes(c.n_deltas, n_rows);
+    }
+    MECHA_REQUIRE(c.workspace != nullptr && c.workspace_bytes >= need && mecha_aligned16(c.workspace),
+                  "TIES workspace too small or unaligned: need %zu bytes, got %zu", need, c.workspace_bytes);
     if (c.keep_bits != nullptr) MECHA_REQUIRE(!batched && c.base == nullptr, "DARE masks are supported on the per-key delta form only");
 
     bool vec = mecha_aligned16(c.out) && (c.base == nullptr || mecha_aligned16(c.base));
@@ -1097,7 +1261,7 @@ int run_ties(const TiesCall &c) {
     const char *env = getenv("MECHA_TIES_SELECT");
     const bool force_radix = env != nullptr && strcmp(env, "radix") == 0;
     const int force_fail = (env != nullptr && strcmp(env, "fail") == 0) ? 1 : 0;
-    const bool bracket = !dare && !force_radix;
+    const bool bracket = !dare && !force_radix && !c.model_stock;     // the stock kernels want final thresholds before they run
 
     TiesParams p{};
     p.base = c.base;
@@ -1141,7 +1305,27 @@ int run_ties(const TiesCall &c) {
     x.has_rescale = dare && c.rescale;
     x.rescale_div = 1.0f - c.probability;                 // 1.0 - probability as fp32 tensor arithmetic (ties.py:49)
 
-    if (!bracket) {
+    if (c.model_stock) {
+        StockParams sp{};
+        sp.row_len = c.row_len; sp.n_rows = n_rows; sp.cos_eps = c.cos_eps;
+        sp.sums = reinterpret_cast<double *>(ws + w.total);
+        sp.t = reinterpret_cast<float *>(ws + w.total + align_up(sizeof(double) * (size_t)n_rows * (2 * c.n_deltas - 1), 256));
+        MECHA_CHECK_HIP(hipMemsetAsync(sp.sums, 0, sizeof(double) * (size_t)n_rows * (2 * c.n_deltas - 1), s));
+        const int64_t vecs = (c.numel + 7) / 8;
+        const unsigned sgrid = (unsigned)((vecs + MECHA_BLOCK - 1) / MECHA_BLOCK < MECHA_MAX_GRID ? (vecs + MECHA_BLOCK - 1) / MECHA_BLOCK : MECHA_MAX_GRID);
+        const unsigned tgrid = (unsigned)((n_rows + MECHA_BLOCK - 1) / MECHA_BLOCK);
+        if (dare) {
+            launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s);
+            MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_reduce_kernel<true>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, c.vote_sgn, c.flags);
+            MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas);
+            MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<true>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, c.out, c.flags);
+        } else {
+            launch_radix<false>(p, grid, one_minus_k, c.thresholds_out, s);
+            MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_reduce_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, c.vote_sgn, c.flags);
+            MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas);
+            MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, c.out, c.flags);
+        }
+    } else if (!bracket) {
         if (dare) { launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s); launch_merge<true>(p, x, grid, c.out, c.flags, s); }
         else { launch_radix<false>(p, grid, one_minus_k, c.thresholds_out, s); launch_merge<false>(p, x, grid, c.out, c.flags, s); }
     } else {
@@ -1219,6 +1403,24 @@ int mecha_ties_sum_with_dropout(const void *const *deltas, int n_models, const u
     TiesCall c{};
     c.inputs = deltas; c.n_deltas = n_models; c.keep_bits = keep_bits; c.out = out; c.numel = numel; c.in_dt = in_dtype;
     c.out_dt = out_dtype; c.k = k; c.vote_sgn = vote_sgn; c.probability = probability; c.rescale = rescale;
+    c.thresholds_out = thresholds_out; c.workspace = workspace; c.workspace_bytes = workspace_bytes; c.flags = flags;
+    c.stream = stream;
+    return run_ties(c);
+}
+
+size_t mecha_ties_extended_workspace_bytes(int n_models, int64_t numel, int64_t row_len) {
+    if (n_models < 1) n_models = 1;
+    if (row_len < 1) row_len = 1;
+    return layout(n_models, 1, numel).total + stock_bytes(n_models, (numel + row_len - 1) / row_len);
+}
+
+int mecha_ties_sum_extended(const void *const *deltas, int n_models, const uint32_t *keep_bits, void *out, int64_t numel, int64_t row_len,
+                            int in_dtype, int out_dtype, double k, int vote_sgn, int model_stock, float cos_eps, float probability,
+                            int rescale, float *thresholds_out, void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream) {
+    TiesCall c{};
+    c.inputs = deltas; c.n_deltas = n_models; c.keep_bits = keep_bits; c.out = out; c.numel = numel; c.in_dt = in_dtype;
+    c.out_dt = out_dtype; c.k = k; c.vote_sgn = vote_sgn; c.probability = probability; c.rescale = rescale;
+    c.model_stock = model_stock; c.cos_eps = cos_eps; c.row_len = row_len;
     c.thresholds_out = thresholds_out; c.workspace = workspace; c.workspace_bytes = workspace_bytes; c.flags = flags;
     c.stream = stream;
     return run_ties(c);

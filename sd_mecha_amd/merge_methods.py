@@ -320,25 +320,74 @@ def dare_draw_masks(seed: int, probability: float, n_models: int, numel: int, de
     return host.to(device, non_blocking=False)
 
 
+def _ties_extended(ds, keep_bits, k, vote_sgn, model_stock, cos_eps, probability, rescale, out_dtype, flags, check_finite,
+                   return_thresholds=False):
+    n, numel = len(ds), ds[0].numel()
+    if model_stock:
+        if ds[0].dim() < 1:
+            raise ValueError("the model-stock factor takes the cosine along the last dimension: 0-d keys have none "
+                             "(torch.nn.CosineSimilarity(dim=-1) raises in the reference)")
+        if not 2 <= n <= 8:
+            raise NotImplementedError(f"the model-stock factor on MI355X takes 2..8 deltas (got {n}; the reference itself raises for 1)")
+    row_len = ds[0].shape[-1] if ds[0].dim() >= 1 else 1
+    if keep_bits is not None:
+        if keep_bits.dtype != torch.int32 or tuple(keep_bits.shape) != (n, (numel + 31) // 32) or keep_bits.device != ds[0].device:
+            raise ValueError("keep_bits must be int32 [n_models, ceil(numel/32)] on the deltas' device")
+        keep_bits = _c(keep_bits)
+    out = _out(ds[0], out_dtype)
+    L = _lib.lib()
+    ws = _workspace(L.mecha_ties_extended_workspace_bytes(n, numel, row_len), out.device)
+    thr = _thresholds(n, out.device, return_thresholds)
+    fl = _Flags(out.device, flags, check_finite)
+    _lib.check(L.mecha_ties_sum_extended(_lib.ptr_array([d.data_ptr() for d in ds]), n, keep_bits.data_ptr() if keep_bits is not None else None,
+                                         out.data_ptr(), numel, row_len, _DT[ds[0].dtype], _DT[out.dtype], float(k), int(bool(vote_sgn)),
+                                         int(bool(model_stock)), float(cos_eps), float(probability), int(bool(rescale)),
+                                         thr.data_ptr() if thr is not None else None, ws.data_ptr(), ws.numel(), fl.ptr, _stream()),
+               "mecha_ties_sum_extended")
+    fl.finish(None)
+    return (out, thr) if return_thresholds else out
+
+
+def ties_sum_extended(*models, k: float = 0.2, vote_sgn: bool = False, apply_stock: bool = False, apply_median: bool = False,
+                      cos_eps: float = 1e-6, eps: float = 1e-6, maxiter: int = 100, ftol: float = 1e-20, out_dtype=None, flags=None,
+                      check_finite=True):
+    """ties_sum_extended (ties.py:68-94) with apply_median == False.  apply_stock == False (the default) APPLIES the
+    model-stock factor (ties.py:90, restated literally)."""
+    if not models:
+        return 0
+    if apply_median:
+        raise NotImplementedError("the geometric median (ties.py:162-199) stays on the reference")
+    ds = [_c(m) for m in models]
+    _check_inputs(ds, "ties_sum_extended")
+    if ds[0].numel() == 0:
+        return ds[0]
+    return _ties_extended(ds, None, k, vote_sgn, not apply_stock, cos_eps, 0.0, False, out_dtype, flags, check_finite)
+
+
 def ties_sum_with_dropout(*deltas, probability=0.9, della_eps: float = 0.0, rescale: bool = True, k: float = 0.2,
                           vote_sgn: bool = False, apply_stock: bool = False, cos_eps: float = 1e-6, apply_median: bool = False,
                           eps: float = 1e-6, maxiter: int = 100, ftol: float = 1e-20, seed: Optional[int] = None,
                           out_dtype=None, flags=None, check_finite=True, keep_bits: Optional[torch.Tensor] = None):
-    """DARE: ties_sum_with_dropout (ties.py:10-50).  In scope on MI355X: della_eps == 0, apply_median == False and
-    apply_stock == True (t = 1, ties.py:90 -- note the reference APPLIES the model-stock factor when apply_stock is
-    False); anything else raises NotImplementedError.  Masks follow the reference's CPU generator stream for
-    seed >= 0 (pass ``keep_bits`` to supply your own)."""
+    """DARE: ties_sum_with_dropout (ties.py:10-50).  In scope on MI355X: della_eps == 0 and apply_median == False.
+    Note ties.py:90: the reference APPLIES the model-stock factor when apply_stock is False (its default); that path takes
+    2..8 deltas of at least one dimension.  Masks follow the reference's CPU generator stream for seed >= 0 (pass
+    ``keep_bits`` to supply your own)."""
     p = _alpha(probability)
     if not deltas or math.isclose(p, 1.0):
         return 0
-    if not math.isclose(della_eps, 0.0) or apply_median or not apply_stock:
-        raise NotImplementedError("MI355X DARE path covers della_eps == 0, apply_median == False, apply_stock == True "
-                                  "(SURVEY §8 a15 / §8f-4); other settings stay on the reference")
+    if not math.isclose(della_eps, 0.0) or apply_median:
+        raise NotImplementedError("MI355X DARE path covers della_eps == 0 and apply_median == False (SURVEY §8 a15); "
+                                  "DELLA ranks and the geometric median stay on the reference")
     ds = [_c(d) for d in deltas]
     _check_inputs(ds, "ties_sum_with_dropout")
     if ds[0].numel() == 0:
         return ds[0]
     n, numel = len(ds), ds[0].numel()
+    if not apply_stock:
+        if seed is None or seed < 0:
+            seed = int(torch.seed() & 0xFFFFFFFF)
+        bits = keep_bits if keep_bits is not None else dare_draw_masks(seed, p, n, numel, ds[0].device)
+        return _ties_extended(ds, bits, k, vote_sgn, True, cos_eps, p, rescale, out_dtype, flags, check_finite)
     if keep_bits is None:
         if seed is None or seed < 0:
             seed = int(torch.seed() & 0xFFFFFFFF)          # unseeded generator (ties.py:29-31)

@@ -139,8 +139,15 @@ def test_golden_dare(amd, oracle):
             want = f32_from_bits(g[f"{pre}_stock1_rescale{int(rescale)}"]).reshape(deltas[0].shape)
             got = amd.ties_sum_with_dropout(*deltas, probability=p, rescale=rescale, k=0.5, apply_stock=True, seed=seed)
             assert ulp_distance_f32(host_f32(got), want).max() <= 1
+        # apply_stock=False (the reference default) APPLIES the model-stock factor (ties.py:90); it goes through torch
+        # reductions whose order is not fixed: same bound as the oracle's own golden test
+        if deltas[0].dim() >= 1 and len(deltas) >= 2:
+            for rescale in (True, False):
+                want = f32_from_bits(g[f"{pre}_stock0_rescale{int(rescale)}"]).reshape(deltas[0].shape)
+                got = amd.ties_sum_with_dropout(*deltas, probability=p, rescale=rescale, k=0.5, apply_stock=False, seed=seed)
+                assert np.allclose(host_f32(got), want, rtol=2e-5, atol=1e-9), (pre, rescale)
         with pytest.raises(NotImplementedError):
-            amd.ties_sum_with_dropout(*deltas, probability=p, k=0.5, apply_stock=False, seed=seed)
+            amd.ties_sum_with_dropout(*deltas, probability=p, k=0.5, apply_median=True, seed=seed)
     assert amd.ties_sum_with_dropout(probability=0.5) == 0
     assert amd.ties_sum_with_dropout(torch.zeros(4, device="cuda"), probability=1.0) == 0
 
@@ -261,6 +268,27 @@ def test_ties_heavy_ties_and_skewed_keys(amd, oracle, levels):
             got, thr = amd.ties_sum(*[dev(d, "float32") for d in deltas], k=k, return_thresholds=True)
             assert np.array_equal(host_bits(thr), det["thresholds"].view(np.uint32)), (name, k, "thresholds")
             assert np.array_equal(host_bits(got), want.view(np.uint32)), (name, k, "output")
+
+
+@pytest.mark.parametrize("shape", [(5000,), (300, 1280), (64, 32, 3, 3), (7, 1), (1000, 9)])
+def test_ties_sum_extended_model_stock_vs_oracle(amd, oracle, shape):
+    """ties_sum_extended with the model-stock factor (ties.py:68-94, :146-159): per-row cosines along the last dimension
+    (rows of 1, 3, 9, 1280 and 5000 elements: lanes that span several rows, rows that span several waves)."""
+    rng = np.random.default_rng(len(shape) * 100 + shape[-1])
+    for n_models in (2, 3, 5):
+        common = rng.normal(0, 0.02, size=shape).astype(np.float32)
+        deltas = [(common + rng.normal(0, 0.01, size=shape)).astype(np.float32) for _ in range(n_models)]      # correlated: cos away from 0
+        want = oracle.ties_sum_extended(deltas, k=0.3, apply_stock=False)
+        got = amd.ties_sum_extended(*[dev(d, "float32") for d in deltas], k=0.3, apply_stock=False)
+        assert got.shape == tuple(shape)
+        assert np.allclose(host_f32(got), want, rtol=2e-5, atol=1e-9), (shape, n_models, np.abs(host_f32(got) - want).max())
+        # apply_stock=True is plain ties_sum
+        plain = amd.ties_sum_extended(*[dev(d, "float32") for d in deltas], k=0.3, apply_stock=True)
+        assert np.array_equal(host_bits(plain), host_bits(amd.ties_sum(*[dev(d, "float32") for d in deltas], k=0.3)))
+    with pytest.raises(NotImplementedError):
+        amd.ties_sum_extended(dev(deltas[0], "float32"), k=0.3)                              # one delta: the reference raises too
+    with pytest.raises(ValueError):
+        amd.ties_sum_extended(torch.tensor(1.0, device="cuda"), torch.tensor(2.0, device="cuda"))
 
 
 def test_reductions_vs_oracle(amd, oracle):
