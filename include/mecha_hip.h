@@ -237,6 +237,23 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
 size_t mecha_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols);
 int mecha_rotate(const void *a, const void *b, void *out, int64_t n_rows, int64_t n_cols, int in_dtype, int out_dtype,
                  float centralization, void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);
+/* rotate with the reference's other whole-number settings and its factor cache (svd.py:55-85):
+ *   alignment in {-1, 0, 1}: the power of the transform applied to `a` (svd.py:84; FullRankOrthogonalMatmul :198-203 with
+ *     fractional_orthogonal_matrix_power :209-215, LowRankOrthogonalMatmul :177-183); the mean added back is
+ *     lerp(a_mean, b_mean, alignment) (svd.py:85).  Fractional alignment (eigendecomposition / Stiefel log, :216-219,
+ *     :184-188) is outside this path and is refused.
+ *   alpha (scalar): a_2d = lerp(a_2d, transform(b_2d, -1), alpha) before the transform is applied (svd.py:81-82);
+ *     fused into the epilogue of the GEMM that forms transform(b_2d, -1).  alignment == 0 with alpha == 0 is refused
+ *     (the shim returns `a`, svd.py:39-40).
+ *   transform_out (DEVICE fp32, may be NULL): receives the transform, mecha_rotate_transform_floats(n_rows, n_cols)
+ *     floats: R (n_cols x n_cols) for n_rows >= n_cols, else Qb^T then Z (n_rows x n_cols each; U V^T = Z^T Qb^T).
+ *   transform_in (DEVICE fp32, 16-byte aligned, may be NULL): a transform saved earlier for the same key and
+ *     centralization; the Procrustes solve is skipped (svd.py:74-75 `cache["transform"]`).  The shim keeps the saved
+ *     copy on the host in fp16 as the reference does (svd.py:79). */
+int64_t mecha_rotate_transform_floats(int64_t n_rows, int64_t n_cols);
+int mecha_rotate_ex(const void *a, const void *b, void *out, int64_t n_rows, int64_t n_cols, int in_dtype, int out_dtype,
+                    float centralization, int alignment, float alpha, const float *transform_in, float *transform_out,
+                    void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);
 int mecha_allclose_half(const void *a, const void *b, int64_t numel, int in_dtype, uint32_t *not_close, void *stream);
 
 /* ------------------------------------------------------------------ batched

@@ -367,7 +367,7 @@ def orthogonal_procrustes(a2: np.ndarray, b2: np.ndarray):
 
 
 def rotate(a, b, alignment: float = 1.0, alpha: float = 0.0, centralization: float = 1.0, return_transform: bool = False):
-    """svd.py:10-86 at integer alignment (0 or 1) -- the in-scope configuration."""
+    """svd.py:10-86 at alignment in {-1, 0, 1} -- the in-scope configurations."""
     a, b = _f32(a), _f32(b)
     alpha = float(np.float32(alpha))
     if isclose(alignment, 0.0) and isclose(alpha, 0.0):
@@ -377,7 +377,7 @@ def rotate(a, b, alignment: float = 1.0, alpha: float = 0.0, centralization: flo
     # torch.allclose(a.half(), b.half()): rtol 1e-5, atol 1e-8, evaluated in fp16
     if a.ndim <= 1 or np.allclose(a.astype(np.float16).astype(np.float32), b.astype(np.float16).astype(np.float32), rtol=1e-5, atol=1e-8):
         return lerp(a, b, alpha)
-    if not (isclose(alignment, 1.0) or isclose(alignment, 0.0)):
+    if not (isclose(alignment, 1.0) or isclose(alignment, 0.0) or isclose(alignment, -1.0)):
         raise NotImplementedError("fractional alignment is out of scope (SURVEY §8 a16)")
     shape_2d = rotate_shape_2d(a.shape)
     a2 = a.reshape(shape_2d).astype(np.float64)

@@ -5,6 +5,8 @@ Public surface mirrors the reference for this path only: the bui
 ``StateDictKeyError`` / ``NonFiniteStateDictKeyError``, ``model()``, ``literal()``, ``merge()``, ``serialize()``
 and the ``@merge_method`` decorator for user-defined per-key methods.
 """
+import collections as _collections
+
 from . import merge_methods as _mm
 from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError, dare_draw_masks  # noqa: F401
 from .recipe_nodes import (  # noqa: F401
@@ -41,7 +43,7 @@ add_difference_ties = merge_method(_mm.add_difference_ties)
 cast = merge_method(_mm.cast)
 omit_non_finite = merge_method(_mm.omit_non_finite)
 fallback = merge_method(_fallback, identifier="fallback")
-rotate = merge_method(_mm.rotate)
+rotate = merge_method(_mm.rotate, cache_factory=lambda: _collections.defaultdict(dict))   # svd.py:10
 lora_merge = merge_method(_mm.lora_merge)
 lora_delta = merge_method(_mm.lora_delta)
 

@@ -62,14 +62,17 @@ __global__ __launch_bounds__(256) void rot_colsum_kernel(const void *a, const vo
     if (bad && flags != nullptr) atomicOr(flags, MECHA_FLAG_INPUT_NONFINITE);
 }
 
-__global__ __launch_bounds__(256) void rot_means_kernel(const double *part, int chunks, int64_t n, int64_t p, float cz,
-                                                        float *a_mean, float *b_mean) {
+__global__ __launch_bounds__(256) void rot_means_kernel(const double *part, int chunks, int64_t n, int64_t p, float cz, float t,
+                                                        float *a_mean, float *b_mean, float *t_mean) {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= p) return;
     double sa = 0.0, sb = 0.0;
     for (int k = 0; k < chunks; k++) { sa += part[((int64_t)0 * chunks + k) * p + col]; sb += part[((int64_t)1 * chunks + k) * p + col]; }
     a_mean[col] = (float)(sa / (double)n) * cz;          // a_2d.mean(0) * centralization  (svd.py:67)
     b_mean[col] = (float)(sb / (double)n) * cz;
+    // torch.lerp(a_mean, b_mean, alignment)  (svd.py:85; Lerp.h:12-34)
+    const float am = a_mean[col], bm = b_mean[col];
+    t_mean[col] = fabsf(t) < 0.5f ? __builtin_fmaf(t, bm - am, am) : bm - (bm - am) * (1.0f - t);
 }
 
 __global__ __launch_bounds__(256) void rot_center_kernel(const void *a, const void *b, int dt, int64_t n, int64_t p, const float *a_mean,
@@ -95,6 +98,8 @@ struct GemmEpilogue {
     uint32_t *flags;
     const float *axpy;          // if set: v = axpy_a * axpy[idx] + axpy_b * v   (the Newton-Schulz update), applied first
     float axpy_a, axpy_b;
+    const float *mix;           // if set: v = mix_w0 * mix[idx] + mix_w1 * v, after minus / plus (the alpha interpolation, svd.py:82)
+    float mix_w0, mix_w1;
 };
 
 __device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int64_t ldc, int64_t row, int64_t col, float v, bool &bad) {
@@ -102,6 +107,7 @@ __device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int6
     if (e.axpy != nullptr) v = __builtin_fmaf(e.axpy_a, e.axpy[idx], e.axpy_b * v);
     if (e.minus != nullptr) v = v - e.minus[idx];
     if (e.plus != nullptr) v = e.plus[idx] + v;
+    if (e.mix != nullptr) v = __builtin_fmaf(e.mix_w0, e.mix[idx], e.mix_w1 * v);
     if (e.col_bias != nullptr) v = v + e.col_bias[col];
     if (e.out != nullptr) {
         bad |= nonfinite_f32(v);
@@ -358,11 +364,11 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
 size_t rotate_workspace_bytes_impl(int64_t n, int64_t p) {
     const size_t q = (size_t)(n < p ? n : p);
     size_t b = 4096;
-    b += up256(sizeof(double) * 2 * 64 * p) + 2 * up256(sizeof(float) * p);
-    b += 2 * up256(sizeof(float) * n * p);                      // Ac, Bc
+    b += up256(sizeof(double) * 2 * 64 * p) + 3 * up256(sizeof(float) * p);
+    b += 3 * up256(sizeof(float) * n * p);                      // Ac, Bc, and the alpha-interpolated copy
     b += up256(sizeof(float) * SLAB_FLOATS);
     if (n >= p) b += 4 * up256(sizeof(float) * p * p);          // M -> R, its Newton-Schulz twin, G, b G + c G^2
-    else b += 3 * up256(sizeof(float) * q * p) + 5 * up256(sizeof(float) * q * q);   // Qb^T, Z, twin; G, b G + c G^2, P, Ac Qb, D
+    else b += 3 * up256(sizeof(float) * q * p) + 5 * up256(sizeof(float) * q * q);   // Qb^T, Z, twin; G, b G + c G^2, P, x P2^T, D
     return b;
 }
 
@@ -376,64 +382,117 @@ size_t mecha_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols) {
     return rotate_workspace_bytes_impl(n_rows, n_cols);
 }
 
-int mecha_rotate(const void *a, const void *b, void *out, int64_t n, int64_t p, int in_dtype, int out_dtype, float centralization,
-                 void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream) {
+int64_t mecha_rotate_transform_floats(int64_t n_rows, int64_t n_cols) {
+    if (n_rows < 1 || n_cols < 1) return 0;
+    return n_rows >= n_cols ? n_cols * n_cols : 2 * n_rows * n_cols;
+}
+
+int mecha_rotate_ex(const void *a, const void *b, void *out, int64_t n, int64_t p, int in_dtype, int out_dtype, float centralization,
+                    int alignment, float alpha, const float *transform_in, float *transform_out, void *workspace,
+                    size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream) {
     MECHA_REQUIRE(a != nullptr && b != nullptr && out != nullptr, "NULL tensor pointer");
     MECHA_REQUIRE(n >= 1 && p >= 1, "rotate needs a non-empty 2-D key (got %lld x %lld)", (long long)n, (long long)p);
     MECHA_REQUIRE(mecha_valid_dtype(in_dtype) && mecha_valid_dtype(out_dtype), "unknown dtype code");
+    MECHA_REQUIRE(alignment >= -1 && alignment <= 1, "rotate: alignment must be -1, 0 or 1 (fractional powers are outside this path), got %d", alignment);
+    MECHA_REQUIRE(alpha == alpha, "rotate: alpha is NaN");
+    const bool has_alpha = alpha != 0.0f;
+    MECHA_REQUIRE(alignment != 0 || has_alpha, "rotate: alignment == 0 with alpha == 0 is the identity (svd.py:39-40); return a instead");
     const size_t need = rotate_workspace_bytes_impl(n, p);
     MECHA_REQUIRE(workspace != nullptr && workspace_bytes >= need && mecha_aligned16(workspace),
                   "rotate workspace too small or unaligned: need %zu bytes, got %zu", need, workspace_bytes);
+    MECHA_REQUIRE(transform_in == nullptr || mecha_aligned16(transform_in), "rotate: transform_in must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Bump ws{static_cast<char *>(workspace), 0};
     const int chunks = (int)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
     double *scal = ws.take<double>(8);
     double *part = ws.take<double>((size_t)2 * 64 * p);
-    float *a_mean = ws.take<float>(p), *b_mean = ws.take<float>(p);
-    float *ac = ws.take<float>(n * p), *bc = ws.take<float>(n * p);
+    float *a_mean = ws.take<float>(p), *b_mean = ws.take<float>(p), *t_mean = ws.take<float>(p);
+    float *ac = ws.take<float>(n * p), *bc = ws.take<float>(n * p), *y = ws.take<float>(n * p);
     float *slabs = ws.take<float>(SLAB_FLOATS);
     if (sweeps_out) *sweeps_out = 0;
 
     hipLaunchKernelGGL(rot_colsum_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)chunks), dim3(256), 0, s, a, b, in_dtype, n, p, chunks, part, flags);
-    hipLaunchKernelGGL(rot_means_kernel, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, s, part, chunks, n, p, centralization, a_mean, b_mean);
+    hipLaunchKernelGGL(rot_means_kernel, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, s, part, chunks, n, p, centralization,
+                       (float)alignment, a_mean, b_mean, t_mean);
     const int64_t total = n * p;
     const unsigned cb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(rot_center_kernel, dim3(cb), dim3(256), 0, s, a, b, in_dtype, n, p, a_mean, b_mean, ac, bc);
 
     const GemmEpilogue none{};
-    GemmEpilogue fin{};
-    fin.col_bias = b_mean; fin.out = out; fin.out_dt = out_dtype; fin.flags = flags;
+    GemmEpilogue fin{};                                         // + lerp(a_mean, b_mean, alignment), cast, finite flag  (svd.py:85-86)
+    fin.col_bias = t_mean; fin.out = out; fin.out_dt = out_dtype; fin.flags = flags;
     int rc;
     constexpr int MAX_ITERS = 100;
     if (n >= p) {
         float *R = ws.take<float>(p * p), *twin = ws.take<float>(p * p), *G = ws.take<float>(p * p), *G2 = ws.take<float>(p * p);
-        // M = Ac^T Bc:  M[i][j] = sum_r Ac[r][i] Bc[r][j];  R = U V^T = the orthogonal polar factor of M
-        gemm(Operand{ac, p, 1}, Operand{bc, p, 1}, R, p, p, n, slabs, none, s);
-        if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
-        // out[r][j] = sum_i Ac[r][i] R[i][j] + b_mean[j]
-        gemm(Operand{ac, 1, p}, Operand{R, p, 1}, nullptr, n, p, p, slabs, fin, s);
+        if (transform_in != nullptr) {
+            MECHA_CHECK_HIP(hipMemcpyAsync(R, transform_in, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
+        } else {
+            // M = Ac^T Bc:  M[i][j] = sum_r Ac[r][i] Bc[r][j];  R = U V^T = the orthogonal polar factor of M
+            gemm(Operand{ac, p, 1}, Operand{bc, p, 1}, R, p, p, n, slabs, none, s);
+            if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
+        }
+        if (transform_out != nullptr) MECHA_CHECK_HIP(hipMemcpyAsync(transform_out, R, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
+        const float *src = ac;
+        if (has_alpha) {
+            // lerp(Ac, Bc R^T, alpha)  (svd.py:81-82; transform(b_2d, -1) = b_2d @ R.mH):  (Bc R^T)[r][i] = sum_j Bc[r][j] R[i][j]
+            GemmEpilogue e = alignment == 0 ? fin : none;
+            e.axpy = ac; e.axpy_a = 1.0f - alpha; e.axpy_b = alpha;
+            gemm(Operand{bc, 1, p}, Operand{R, 1, p}, y, n, p, p, slabs, e, s);
+            src = y;
+        }
+        // out[r][j] = sum_i src[r][i] R[i][j] + mean[j]   (alignment 1),  sum_i src[r][i] R[j][i] + mean[j]   (alignment -1)
+        if (alignment == 1) gemm(Operand{src, 1, p}, Operand{R, p, 1}, nullptr, n, p, p, slabs, fin, s);
+        else if (alignment == -1) gemm(Operand{src, 1, p}, Operand{R, 1, p}, nullptr, n, p, p, slabs, fin, s);
     } else {
         float *qbt = ws.take<float>(n * p), *z = ws.take<float>(n * p), *twin = ws.take<float>(n * p);
-        float *G = ws.take<float>(n * n), *G2 = ws.take<float>(n * n), *P = ws.take<float>(n * n), *aq = ws.take<float>(n * n), *D = ws.take<float>(n * n);
-        // Qb^T = polar factor of Bc: orthonormal rows spanning the row space of Bc (= columns of b.mH)
-        MECHA_CHECK_HIP(hipMemcpyAsync(qbt, bc, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-        if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
-        // T^T = Bc Qb =: P (n x n):  P[r][k] = sum_c Bc[r][c] Qb^T[k][c]
-        gemm(Operand{bc, 1, p}, Operand{qbt, 1, p}, P, n, n, p, slabs, none, s);
-        // N^T = P^T Ac (n x p):  N^T[k][i] = sum_r P[r][k] Ac[r][i];  N = U S W^T, Z := polar(N^T) = W U^T
-        gemm(Operand{P, n, 1}, Operand{ac, p, 1}, z, n, p, n, slabs, none, s);
-        if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
-        // with V = Qb W:  U V^T = Z^T Qb^T and V V^T = Qb Qb^T, so  out = Ac + (Ac Z^T - Ac Qb) Qb^T + b_mean
-        gemm(Operand{ac, 1, p}, Operand{qbt, 1, p}, aq, n, n, p, slabs, none, s);              // aq[r][k] = sum_c Ac[r][c] Qb^T[k][c]
-        GemmEpilogue minus_aq{};
-        minus_aq.minus = aq;
-        gemm(Operand{ac, 1, p}, Operand{z, 1, p}, D, n, n, p, slabs, minus_aq, s);             // D = Ac Z^T - Ac Qb
-        // out[r][c] = Ac[r][c] + sum_k D[r][k] Qb^T[k][c] + b_mean[c]
-        fin.plus = ac;
-        gemm(Operand{D, 1, n}, Operand{qbt, p, 1}, nullptr, n, p, n, slabs, fin, s);
+        float *G = ws.take<float>(n * n), *G2 = ws.take<float>(n * n), *P = ws.take<float>(n * n), *xq = ws.take<float>(n * n), *D = ws.take<float>(n * n);
+        if (transform_in != nullptr) {
+            MECHA_CHECK_HIP(hipMemcpyAsync(qbt, transform_in, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+            MECHA_CHECK_HIP(hipMemcpyAsync(z, transform_in + n * p, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+        } else {
+            // Qb^T = polar factor of Bc: orthonormal rows spanning the row space of Bc (= columns of b.mH)
+            MECHA_CHECK_HIP(hipMemcpyAsync(qbt, bc, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+            if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
+            // T^T = Bc Qb =: P (n x n):  P[r][k] = sum_c Bc[r][c] Qb^T[k][c]
+            gemm(Operand{bc, 1, p}, Operand{qbt, 1, p}, P, n, n, p, slabs, none, s);
+            // N^T = P^T Ac (n x p):  N^T[k][i] = sum_r P[r][k] Ac[r][i];  N = U S W^T, Z := polar(N^T) = W U^T
+            gemm(Operand{P, n, 1}, Operand{ac, p, 1}, z, n, p, n, slabs, none, s);
+            if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, slabs, MAX_ITERS, sweeps_out, s)) != MECHA_OK) return rc;
+        }
+        if (transform_out != nullptr) {
+            MECHA_CHECK_HIP(hipMemcpyAsync(transform_out, qbt, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+            MECHA_CHECK_HIP(hipMemcpyAsync(transform_out + n * p, z, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+        }
+        // With V = Qb W (the reference's v) and U (its u):  U V^T = Z^T Qb^T,  V V^T = Qb Qb^T,  U U^T = Z^T Z,  V U^T = Qb Z.  So
+        //   transform(x, +1) = x - x V V^T + x U V^T = x + (x Z^T - x Qb) Qb^T      (svd.py:181)   -> low_rank(x, Z, Qb^T)
+        //   transform(x, -1) = x - x U U^T + x V U^T = x + (x Qb - x Z^T) Z         (svd.py:183)   -> low_rank(x, Qb^T, Z)
+        auto low_rank = [&](const float *x, const float *P1, const float *P2, float *C, GemmEpilogue e) {
+            gemm(Operand{x, 1, p}, Operand{P2, 1, p}, xq, n, n, p, slabs, none, s);         // xq[r][k] = sum_c x[r][c] P2[k][c]
+            GemmEpilogue minus_xq{};
+            minus_xq.minus = xq;
+            gemm(Operand{x, 1, p}, Operand{P1, 1, p}, D, n, n, p, slabs, minus_xq, s);      // D = x P1^T - x P2^T
+            e.plus = x;
+            gemm(Operand{D, 1, n}, Operand{P2, p, 1}, C, n, p, n, slabs, e, s);             // C[r][c] = x[r][c] + sum_k D[r][k] P2[k][c]
+        };
+        const float *src = ac;
+        if (has_alpha) {
+            GemmEpilogue e = alignment == 0 ? fin : none;
+            e.mix = ac; e.mix_w0 = 1.0f - alpha; e.mix_w1 = alpha;                          // lerp(Ac, transform(Bc, -1), alpha)
+            low_rank(bc, qbt, z, y, e);
+            src = y;
+        }
+        if (alignment == 1) low_rank(src, z, qbt, nullptr, fin);
+        else if (alignment == -1) low_rank(src, qbt, z, nullptr, fin);
     }
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;
+}
+
+int mecha_rotate(const void *a, const void *b, void *out, int64_t n, int64_t p, int in_dtype, int out_dtype, float centralization,
+                 void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream) {
+    return mecha_rotate_ex(a, b, out, n, p, in_dtype, out_dtype, centralization, 1, 0.0f, nullptr, nullptr, workspace, workspace_bytes,
+                           sweeps_out, flags, stream);
 }
 
 // torch.allclose(a.half(), b.half()) of svd.py:46.  ORs 1 into *not_close (device word, zeroed by the caller) if any element differs.

@@ -526,9 +526,10 @@ def rotate_shape_2d(shape) -> tuple:
 def rotate(a, b, alignment: float = 1.0, alpha=0.0, centralization: float = 1.0, stiefel_eps: float = 1e-8,
            stiefel_max_iters: int = 100, *, key=None, cache=None, out_dtype=None, flags=None, check_finite=True,
            return_sweeps: bool = False):
-    """rotate (svd.py:10-86).  On the MI355X path: alignment in {0, 1} with alpha == 0 (the benchmark
-    configuration); the early-outs of svd.py:37-47 are kept; fractional alignment, alpha != 0 and the ``cache`` of
-    factors raise NotImplementedError."""
+    """rotate (svd.py:10-86).  On the MI355X path: alignment in {-1, 0, 1}, scalar alpha, and the factor ``cache``
+    (svd.py:55-79: a dict per key holding the transform in fp16 on the host and the centralization it was made for);
+    the early-outs of svd.py:37-47 are kept.  Fractional alignment (matrix logarithms / eigendecompositions,
+    svd.py:184-188, :216-236) and per-element alpha raise NotImplementedError."""
     al = _alpha(alpha)
     if math.isclose(alignment, 0.0) and math.isclose(al, 0.0):
         return cast(a, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
@@ -545,16 +546,39 @@ def rotate(a, b, alignment: float = 1.0, alpha=0.0, centralization: float = 1.0,
         same = True
     if a.dim() <= 1 or same:
         return weighted_sum(a, b, al, key=key, out_dtype=out_dtype, flags=flags, check_finite=check_finite)   # torch.lerp(a, b, alpha), svd.py:47
-    if not math.isclose(al, 0.0) or not math.isclose(alignment, 1.0) or cache is not None:
-        raise NotImplementedError("MI355X rotate covers alignment == 1 with alpha == 0 and no factor cache (SURVEY §8 a16)")
+    whole = round(alignment)
+    if not math.isclose(alignment, whole) or whole not in (-1, 0, 1):
+        raise NotImplementedError("MI355X rotate covers alignment in {-1, 0, 1}; fractional powers of the transform "
+                                  "(svd.py:184-188, :216-236) stay on the reference (SURVEY §8 a16)")
     n, p = rotate_shape_2d(a.shape)
+    if cache is not None:                                       # svd.py:55-63
+        cache = cache[key]
+        if "centralization" in cache:
+            if not math.isclose(cache["centralization"], centralization):
+                cache.clear()
+        else:
+            cache["centralization"] = centralization
+    t_floats = int(L.mecha_rotate_transform_floats(n, p))
+    t_in = t_out = None
+    if cache is not None:
+        saved = cache.get("transform")
+        if saved is not None:                                   # svd.py:74-75
+            if saved.numel() != t_floats:
+                raise ValueError(f"rotate: the cached transform of {key!r} has {saved.numel()} elements, this key needs {t_floats}")
+            t_in = saved.to(device=a.device, dtype=torch.float32).contiguous()
+        else:
+            t_out = torch.empty(t_floats, dtype=torch.float32, device=a.device)
     out = _out(a, out_dtype)
     ws = _workspace(L.mecha_rotate_workspace_bytes(n, p), a.device)
     sweeps = ctypes.c_int(0)
     fl = _Flags(a.device, flags, check_finite)
-    _lib.check(L.mecha_rotate(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, _DT[a.dtype], _DT[out.dtype], float(centralization),
-                              ws.data_ptr(), ws.numel(), ctypes.byref(sweeps), fl.ptr, _stream()), "mecha_rotate")
+    _lib.check(L.mecha_rotate_ex(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, _DT[a.dtype], _DT[out.dtype], float(centralization),
+                                 int(whole), float(al), t_in.data_ptr() if t_in is not None else None,
+                                 t_out.data_ptr() if t_out is not None else None, ws.data_ptr(), ws.numel(), ctypes.byref(sweeps),
+                                 fl.ptr, _stream()), "mecha_rotate_ex")
     fl.finish(key)
+    if t_out is not None:
+        cache["transform"] = t_out.to(device="cpu", dtype=torch.float16)     # svd.py:79
     return (out, sweeps.value) if return_sweeps else out
 
 

@@ -343,6 +343,7 @@ def merge(
     omit_non_finite_inputs: bool = True,
     strict_mandatory_keys: bool = False,
     output=None,
+    cache: Optional[Dict[RecipeNode, Any]] = None,
     backend=None,
 ) -> Optional[MutableMapping[str, torch.Tensor]]:
     """Materialise a state dict from a recipe graph (signature subset of reference merging.py:34-54).
@@ -350,7 +351,8 @@ def merge(
     ``output``: a ``.safetensors`` path, a dict-like, or None (a new dict is returned).  ``total_buffer_size`` is the
     byte budget of the pinned staging buffers (the reference's 2**28 read window scaled to a 288 GB device).
     Under ``torch.distributed`` every rank merges its own stripe of keys; with a file output all ranks fill the same
-    file, with a dict output each rank returns its stripe."""
+    file, with a dict output each rank returns its stripe.  ``cache``: {merge node: its method's ``create_cache()`` object}
+    (merging.py:199), handed to the node's body on every key; today ``rotate`` keeps its transforms there (svd.py:55-79)."""
     if merge_dtype != torch.float32:
         raise NotImplementedError("the MI355X kernels compute in float32 (the reference default merge_dtype)")
     if not omit_non_finite_inputs:
@@ -410,7 +412,7 @@ def merge(
                        total_buffer_size, check_finite_output, skipped)
         else:
             _run_generic(recipe, backend, readers, my_items, header, sink, to_file, output_device, output_dtype,
-                         check_finite_output, strict_mandatory_keys, skipped)
+                         check_finite_output, strict_mandatory_keys, skipped, cache or {})
         for k in skipped:
             log.debug("Skipping key: %s", k)
 
@@ -661,7 +663,7 @@ class _null:
 
 # ------------------------------------------------------------------ generic (per key) path
 def _run_generic(recipe, backend, readers, items, header, sink, to_file, output_device, output_dtype, check_finite_output,
-                 strict_mandatory_keys, skipped):
+                 strict_mandatory_keys, skipped, cache):
     """KeyMergeVisitor (merging.py:374-482) for graphs the fuser does not cover: every model value is uploaded,
     cast to fp32 with the fused finite check, and the method bodies run per key on device tensors."""
     dev = backend.device
@@ -697,7 +699,7 @@ def _run_generic(recipe, backend, readers, items, header, sink, to_file, output_
                 return methods.lora_delta(reader[up_k].to(dev), reader[down_k].to(dev), alpha, tuple(meta.shape))
             args = [evaluate(a, key) for a in node.args]
             kwargs = {k: evaluate(v, key) for k, v in node.kwargs.items()}
-            return node.merge_method.merge_key(args, kwargs, key)
+            return node.merge_method.merge_key(args, kwargs, key, cache.get(node))
         raise TypeError(type(node))
 
     for key, _ in items:

@@ -87,8 +87,9 @@ class MergeMethod:
     (``__wrapped__``), and ``__call__`` that builds a recipe node when given nodes and runs the body when
     given tensors."""
 
-    def __init__(self, fn: Callable, identifier: Optional[str] = None):
+    def __init__(self, fn: Callable, identifier: Optional[str] = None, cache_factory: Optional[Callable] = None):
         self.__wrapped__ = fn
+        self.cache_factory = cache_factory
         self.identifier = identifier or fn.__name__
         self.signature = inspect.signature(fn)
         self.accepts_kwargs = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in self.signature.parameters.values())
@@ -103,21 +104,29 @@ class MergeMethod:
             return MergeRecipeNode(self, tuple(value_to_node(a) for a in args), {k: value_to_node(v) for k, v in kwargs.items()})
         return self.__wrapped__(*args, **kwargs)
 
-    def merge_key(self, args, kwargs, key: str):
+    def create_cache(self):
+        """merge_methods.py:271: a fresh cache object for one node of this method, or None if the method keeps none."""
+        return self.cache_factory() if self.cache_factory is not None else None
+
+    def merge_key(self, args, kwargs, key: str, cache=None):
         """merge_methods.py:304-337: extra kwargs only if the body declares **kwargs or names them."""
         extra = {}
         if self.accepts_kwargs or "key" in self.signature.parameters:
             extra["key"] = key
+        if self.accepts_kwargs or "cache" in self.signature.parameters:
+            extra["cache"] = cache
         return self.__wrapped__(*args, **kwargs, **extra)
 
 
 _registry: Dict[str, MergeMethod] = {}
 
 
-def merge_method(fn: Optional[Callable] = None, *, identifier: Optional[str] = None, register: bool = True):
-    """``@merge_method`` (merge_methods.py:665-711): wrap a per-key function and register it by identifier."""
+def merge_method(fn: Optional[Callable] = None, *, identifier: Optional[str] = None, register: bool = True,
+                 cache_factory: Optional[Callable] = None):
+    """``@merge_method`` (merge_methods.py:665-711): wrap a per-key function and register it by identifier.
+    ``cache_factory`` as in the reference (svd.py:10: ``lambda: defaultdict(dict)``)."""
     def wrap(f):
-        mm = MergeMethod(f, identifier)
+        mm = MergeMethod(f, identifier, cache_factory)
         if register:
             if mm.identifier in _registry:
                 raise ValueError(f"merge method {mm.identifier!r} is already registered")

@@ -175,6 +175,17 @@ def gen_rotate(out):
             for cz in (1.0, 0.0):
                 res = svd.rotate.__wrapped__(sd(a), sd(b), alignment=1.0, alpha=torch.tensor(alpha), centralization=cz, key="k")
                 out[f"{pre}_out_alpha{alpha}_cz{cz}"] = bits(res)
+        # the other whole-number alignments (svd.py:84-85, :198-215, :177-183) and the factor cache (svd.py:55-79):
+        # the second call reads the transform the first one saved in fp16
+        for alignment, alpha in ((0.0, 0.5), (-1.0, 0.25), (-1.0, 0.0)):
+            for cz in (1.0, 0.0):
+                res = svd.rotate.__wrapped__(sd(a), sd(b), alignment=alignment, alpha=torch.tensor(alpha), centralization=cz, key="k")
+                out[f"{pre}_out_align{alignment}_alpha{alpha}_cz{cz}"] = bits(res)
+        import collections
+        cache = collections.defaultdict(dict)
+        first = svd.rotate.__wrapped__(sd(a), sd(b), alignment=1.0, alpha=torch.tensor(0.0), centralization=1.0, key="k", cache=cache)
+        second = svd.rotate.__wrapped__(sd(a), sd(b), alignment=1.0, alpha=torch.tensor(0.5), centralization=1.0, key="k", cache=cache)
+        out[f"{pre}_out_cached_alpha0.5"] = bits(second)
         if len(shape) >= 2:
             is_conv = len(shape) == 4 and int(np.prod(shape[-2:])) != 1
             s2 = (int(np.prod(shape[:2])), int(np.prod(shape[2:]))) if is_conv else (shape[0], int(np.prod(shape[1:])))

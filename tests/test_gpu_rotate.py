@@ -1,4 +1,4 @@
-"""GPU parity of rotate (sd_mecha_amd/csrc/rotate.hip: f32-MFMA contractions + one-sided Jacobi SVD) against the
+"""GPU parity of rotate (sd_mecha_amd/csrc/rotate.hip: f32-MFMA contractions + Newton-Schulz polar factor) against the
 reference's svd.rotate outputs (tests/golden/rotate.npz) and against the oracle (numpy/LAPACK, float64) at larger sizes.
 Bar (BASELINE.json north_star): <= 1e-3 relative Frobenius error.  Wide keys with centring are compared on the
 component the reference determines (test_oracle_golden.rotate_rel_error, DESIGN.md "rotate: reference indeterminacy")."""
@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
 from conftest import load_golden  # noqa: E402
-from test_oracle_golden import f32_from_bits, rotate_rel_error  # noqa: E402
+from test_oracle_golden import ROTATE_EXTRA_CASES, f32_from_bits, rotate_case_undetermined, rotate_rel_error  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -23,14 +23,37 @@ def test_rotate_golden(oracle):
         pre = f"r{c}"
         a, b = f32_from_bits(g[pre + "_a"]), f32_from_bits(g[pre + "_b"])
         ta, tb = torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b.copy()).cuda()
-        for cz in (1.0, 0.0):
-            want = f32_from_bits(g[f"{pre}_out_alpha0.0_cz{cz}"]).reshape(a.shape)
-            got = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=cz).cpu().numpy()
-            rel = rotate_rel_error(oracle, a, b, got, want, cz)
-            assert rel <= 1e-3, (pre, cz, rel)
+        for alpha in (0.0, 0.5):
+            for cz in (1.0, 0.0):
+                want = f32_from_bits(g[f"{pre}_out_alpha{alpha}_cz{cz}"]).reshape(a.shape)
+                got = amd.rotate(ta, tb, alignment=1.0, alpha=alpha, centralization=cz).cpu().numpy()
+                rel = rotate_rel_error(oracle, a, b, got, want, cz)
+                assert rel <= 1e-3, (pre, alpha, cz, rel)
+        for alignment, alpha, cz in ROTATE_EXTRA_CASES:         # alignment 0 and -1 (svd.py:84-85, :177-183, :209-215)
+            if rotate_case_undetermined(oracle, a.shape, alignment, alpha, cz):
+                continue
+            want = f32_from_bits(g[f"{pre}_out_align{alignment}_alpha{alpha}_cz{cz}"]).reshape(a.shape)
+            got = amd.rotate(ta, tb, alignment=alignment, alpha=alpha, centralization=cz).cpu().numpy()
+            rel = rotate_rel_error(oracle, a, b, got, want, cz, alignment)
+            assert rel <= 1e-3, (pre, alignment, alpha, cz, rel)
+        # the factor cache (svd.py:55-79): the second call reads the transform the first one saved (fp16, on the host)
+        cache = amd.rotate.create_cache()
+        first = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=1.0, key="k", cache=cache)
         if a.ndim >= 2:
+            assert cache["k"]["transform"].dtype == torch.float16 and cache["k"]["transform"].device.type == "cpu"
+            assert cache["k"]["centralization"] == 1.0
+            second, iters = amd.rotate(ta, tb, alignment=1.0, alpha=0.5, centralization=1.0, key="k", cache=cache, return_sweeps=True)
+            assert iters == 0                                   # no Procrustes solve on a cache hit
+            want = f32_from_bits(g[f"{pre}_out_cached_alpha0.5"]).reshape(a.shape)
+            rel = rotate_rel_error(oracle, a, b, second.cpu().numpy(), want, 1.0)
+            assert rel <= 1e-3, (pre, "cached", rel)
+            again = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=1.0, key="k", cache=cache)
+            rel = rotate_rel_error(oracle, a, b, again.cpu().numpy(), first.cpu().numpy(), 1.0)
+            assert rel <= 1e-3
+            amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=0.5, key="k", cache=cache)    # svd.py:59-61: invalidated
+            assert "centralization" not in cache["k"] and "transform" in cache["k"]
             with pytest.raises(NotImplementedError):
-                amd.rotate(ta, tb, alignment=1.0, alpha=0.5)
+                amd.rotate(ta, tb, alignment=0.5, alpha=0.0)
     # early-outs (svd.py:37-47)
     x, y = torch.randn(8, 8, device="cuda"), torch.randn(8, 8, device="cuda")
     assert torch.equal(amd.rotate(x, y, alignment=0.0, alpha=0.0), x)
@@ -64,3 +87,39 @@ def test_rotate_vs_oracle(oracle, shape, cz):
         assert abs(np.linalg.norm(gc) / np.linalg.norm(ac) - 1.0) < 1e-4
     out_bf16 = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=cz, out_dtype=torch.bfloat16)
     assert out_bf16.dtype == torch.bfloat16 and out_bf16.shape == ta.shape
+    for alignment, alpha in ((1.0, 0.3), (0.0, 0.7), (-1.0, 0.0), (-1.0, 0.4)):
+        if rotate_case_undetermined(oracle, shape, alignment, alpha, cz):
+            continue
+        want = oracle.rotate(a, b, alignment=alignment, alpha=alpha, centralization=cz)
+        got = amd.rotate(ta, tb, alignment=alignment, alpha=alpha, centralization=cz)
+        rel = rotate_rel_error(oracle, a, b, got.cpu().numpy(), want, cz, alignment)
+        assert rel <= 1e-3, (shape, cz, alignment, alpha, rel)
+
+
+def test_rotate_recipe_with_cache(oracle, tmp_path):
+    """merge(rotate(a, b), cache={node: create_cache()}) (merging.py:199, svd.py:55-79): the second merge of the same node
+    reuses the transforms of the first (a hyper-parameter sweep over alpha)."""
+    import safetensors.torch
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(77)
+    shapes = {"w.tall": (96, 40), "w.wide": (24, 80), "w.conv": (16, 8, 3, 3), "w.bias": (40,)}
+    sds = []
+    for i in range(2):
+        sd = {k: torch.from_numpy(rng.normal(0, 0.02, size=s).astype(np.float32)).to(torch.bfloat16) for k, s in shapes.items()}
+        safetensors.torch.save_file(sd, str(tmp_path / f"m{i}.safetensors"))
+        sds.append({k: v.float().numpy() for k, v in sd.items()})
+    caches = {}
+    outs = []
+    for alpha in (0.0, 0.5):
+        node = amd.rotate(amd.model(tmp_path / "m0.safetensors"), amd.model(tmp_path / "m1.safetensors"), alignment=1.0, alpha=alpha)
+        if not caches:
+            cache = node.merge_method.create_cache()
+        caches = {node: cache}
+        res = amd.merge(node, cache=caches, output_dtype=torch.float32, merge_device="cuda")
+        outs.append(res)
+        for k in shapes:
+            want = oracle.rotate(sds[0][k], sds[1][k], alignment=1.0, alpha=alpha, centralization=1.0)
+            rel = rotate_rel_error(oracle, sds[0][k], sds[1][k], res[k].cpu().numpy(), want, 1.0)
+            assert rel <= 1e-3, (k, alpha, rel)
+    assert set(cache) == {"w.tall", "w.wide", "w.conv"}          # 1-D keys take the lerp early-out before the cache (svd.py:46-47)
+    assert all(v["transform"].dtype == torch.float16 for v in cache.values())
