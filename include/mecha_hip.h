@@ -204,9 +204,12 @@ int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t col
  * two arenas at the same element offsets.  `keys` (DEVICE) / `keys_host` (HOST copy) hold n_keys
  * entries; key i uses nets[net_begin .. net_begin + net_count) of the DEVICE table `nets`
  * (net_count <= MECHA_MAX_MODELS; networks with weight 0 must be left out by the caller);
- * tile_start = running sum of ceil(rows/64) * ceil(cols/64) over the keys before it.
- * offset % 4 == 0 and cols % 4 == 0 enable the vector path.  `key_flags` (may be NULL): DEVICE
- * uint32[n_keys]. */
+ * tile_start = running sum of ceil(rows/MECHA_LORA_TILE) * ceil(cols/MECHA_LORA_TILE) over the keys before it.
+ * offset % 4 == 0 and cols % 4 == 0 enable the vector path; with cols % 8 == 0, every rank a multiple of 32
+ * and 16-byte aligned factors a key takes the fast kernel.  `nets_host` (HOST copy of `nets`, may be NULL) lets
+ * the call launch only the kernel(s) the batch needs; without it both are launched (each skips the other's tiles).
+ * `key_flags` (may be NULL): DEVICE uint32[n_keys]. */
+#define MECHA_LORA_TILE 128
 typedef struct mecha_lora_key {
     int64_t offset;       /* first element of the key inside the base / output arenas */
     int64_t rows, cols;   /* the key viewed as [out, in_flat] */
@@ -222,8 +225,8 @@ typedef struct mecha_lora_net {
 } mecha_lora_net;
 int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const mecha_lora_key *keys,
                                   const mecha_lora_key *keys_host, int n_keys, const mecha_lora_net *nets,
-                                  int base_dtype, int out_dtype, int lora_dtype, uint32_t *key_flags,
-                                  void *stream);
+                                  const mecha_lora_net *nets_host, int base_dtype, int out_dtype, int lora_dtype,
+                                  uint32_t *key_flags, void *stream);
 
 /* rotate (extensions/builtin/merge_methods/svd.py:10-86) at alignment = 1, alpha = 0 for one key already reshaped to
  * n_rows x n_cols (svd.py:49-53): centre both matrices by their column means * centralization (svd.py:67-70),

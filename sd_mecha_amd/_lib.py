@@ -14,6 +14,7 @@ F32, F16, BF16 = 0, 1, 2
 FLAG_INPUT_NONFINITE = 1
 FLAG_OUTPUT_NONFINITE = 2
 MAX_MODELS = 32
+LORA_TILE = 128          # MECHA_LORA_TILE
 ABI_VERSION = 1
 
 
@@ -73,7 +74,7 @@ SIGNATURES = {
     "mecha_ties_sum_extended": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i64, c_i, c_i, c_d, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_sz, c_p, c_p]),
     "mecha_dare_draw_masks_host": (c_i, [c_u64, c_f, c_i, c_i64, c_p]),
     "mecha_lora_accumulate": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
-    "mecha_batched_lora_accumulate": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "mecha_batched_lora_accumulate": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mecha_rotate_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "mecha_rotate": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p, c_p]),
     "mecha_rotate_transform_floats": (c_i64, [c_i64, c_i64]),

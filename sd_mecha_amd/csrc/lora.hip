@@ -11,17 +11,23 @@
 // The product is computed transposed, D^T = down^T . up^T, with v_mfma_f32_32x32x16_{f16,bf16}:
 //   * B operand = up^T: lane (row r, half h) takes the 8 contiguous k of up[row][.] straight from global memory (16 B);
 //   * A operand = down^T: down is [r, cols], so a lane's 8 k-values of one column are a strided gather.  The block stages
-//     the (32 k) x (64 columns) slab of down through LDS instead: coalesced 16-byte row loads, transposed 2-byte LDS
-//     writes, one 16-byte LDS read per lane and k-step.  The slab of the next k-chunk / network is loaded while the
-//     current one is multiplied (double-buffered LDS, one barrier per chunk);
+//     the (32 k) x (128 columns) slab of down through LDS as it lies in memory (coalesced 16-byte row loads, 16-byte LDS
+//     writes) and the MFMA lanes take their fragments with ds_read_b64_tr_b16, gfx950's transposing LDS read: two 8-byte
+//     reads per k-step and column group.  Rows are 320 B apart so that the 4 k-rows a 16-lane group gathers start 64 B
+//     apart in the 256-B bank row: conflict-free.  The slab of the next k-chunk / network is loaded while the current one
+//     is multiplied (double-buffered LDS, one barrier per chunk);
 //   * each lane ends up with 4 CONTIGUOUS output columns per accumulator group: 8-byte (16-byte for fp32) base loads and
 //     output stores.
 // fp16/bf16 products are exact in fp32; accumulation is fp32 (the reference's sgemm order is BLAS-defined, parity is
 // the <= 1 ulp of the output dtype bar).  Scale is applied AFTER the matmul, in fp32, like the reference.
 //
-// Block = 4 waves, block tile = 64 output rows x 64 output columns, wave tile 32 x 32.  The batched entry point runs
-// every key of a wave in ONE launch: tiles of all keys are numbered consecutively, a block finds its key by binary search
-// in the tile prefix (keys are independent, a few thousand per checkpoint; a launch per key costs more than its tiles).
+// Block = 4 waves, block tile = 128 output rows x 128 output columns, wave tile 64 x 64 (2 x 2 MFMA tiles: 8 MFMAs per
+// 4 operand loads from global memory and 8 from LDS per k-chunk; a 128 x 128 tile pulls 1 byte of factors through L2 per
+// output element and network).  The batched entry point runs every key of a wave in ONE launch: tiles of all keys are
+// numbered consecutively, a block finds its key by binary search in the tile prefix (keys are independent, a few thousand
+// per checkpoint; a launch per key costs more than its tiles).  Workgroups go round-robin over the 8 XCDs, each with its
+// own L2: block b takes tile (b % 8) * ceil(T / 8) + b / 8, so that one XCD works through a contiguous run of tiles and a
+// key's factors are fetched into one L2, not eight.
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -30,11 +36,13 @@ namespace {
 
 constexpr int LORA_MAX_NETS = MECHA_MAX_MODELS;
 constexpr int KC = 32;                 // k-chunk staged per LDS buffer
+constexpr int LORA_TILE = MECHA_LORA_TILE;   // block tile, rows and columns
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct LoraParams {
     const void *base;                  // may be nullptr: delta only
@@ -100,33 +108,44 @@ __device__ __forceinline__ void store4(int dt, bool vec, void *p, int64_t i, int
     }
 }
 
-// one (k-chunk) slab of down for this block: thread t holds k = t / 8, columns 8 * (t % 8) .. + 7
+// one (k-chunk) slab of down for this block: thread t holds k = t / 16 (+ 16), columns 8 * (t % 16) .. + 7
 template <int LDT>
-__device__ __forceinline__ u16x8 load_down(const uint16_t *down, int rank, int64_t cols, int64_t col0, int k0, bool vec_ok, bool check, bool &bad) {
-    const int k = k0 + (threadIdx.x >> 3);
-    const int64_t c = col0 + 8 * (threadIdx.x & 7);
-    u16x8 v;
-    if (k < rank && vec_ok && c + 8 <= cols) {
-        v = *reinterpret_cast<const u16x8 *>(down + (int64_t)k * cols + c);
-    } else {
+__device__ __forceinline__ void load_down(const uint16_t *down, int rank, int64_t cols, int64_t col0, int k0, bool vec_ok, bool check, u16x8 (&v)[2], bool &bad) {
+    const int64_t c = col0 + 8 * (threadIdx.x & 15);
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (k < rank && c + j < cols) ? down[(int64_t)k * cols + c + j] : (uint16_t)0;
-    }
-    if (check) {
+    for (int half = 0; half < 2; half++) {
+        const int k = k0 + (threadIdx.x >> 4) + 16 * half;
+        if (k < rank && vec_ok && c + 8 <= cols) {
+            v[half] = *reinterpret_cast<const u16x8 *>(down + (int64_t)k * cols + c);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) bad |= nonfinite16<LDT>(v[j]);
+            for (int j = 0; j < 8; j++) v[half][j] = (k < rank && c + j < cols) ? down[(int64_t)k * cols + c + j] : (uint16_t)0;
+        }
+        if (check) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) bad |= nonfinite16<LDT>(v[half][j]);
+        }
     }
-    return v;
 }
-// LDS slab layout: [k / 8][column (+1 slot of padding per 8 columns)][k % 8]: a lane's A operand (8 k of one column) is
-// one aligned 16-byte read, consecutive columns are consecutive 16-byte slots, and the transposing 2-byte writes of the
-// 8 column groups of a wave land in 8 different banks (pitch 72 slots = 36 dwords between groups of 8 columns).
-constexpr int SLAB_HALFS = (KC / 8) * 72 * 8;
-__device__ __forceinline__ int slab_index(int k, int col) { return (((k >> 3) * 72 + col + (col >> 3)) << 3) + (k & 7); }
-__device__ __forceinline__ void stage_down(uint16_t *slab, u16x8 v) {
-    const int k = threadIdx.x >> 3, c = 8 * (threadIdx.x & 7);
+// LDS slab: [k][PITCH], as in memory.  PITCH = 128 columns + 32 halfs (64 B): see the header.
+constexpr int PITCH = 160;
+constexpr int SLAB_HALFS = KC * PITCH;
+__device__ __forceinline__ void stage_down(uint16_t *slab, const u16x8 (&v)[2]) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) slab[slab_index(k, c + j)] = v[j];
+    for (int half = 0; half < 2; half++)
+        *reinterpret_cast<u16x8 *>(&slab[((threadIdx.x >> 4) + 16 * half) * PITCH + 8 * (threadIdx.x & 15)]) = v[half];
+}
+// A fragment of k-step s (16 k) for the 32 columns at `col` of the slab: lane (r = lane & 31, h = lane >> 5) gets
+// down[16 s + 8 h + j][col + r], j = 0..7.  ds_read_b64_tr_b16 works per group of 16 lanes: lane 4q + p of a group gives the
+// address of row q, columns 4p..4p+3 of a 4 x 16 block; lane i receives column i, row q in element q.  EXEC must be all ones:
+// every call site is in block-uniform control flow.
+__device__ __forceinline__ u16x8 read_a(const uint16_t *slab, int s, int col) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = i >> 2, pp = i & 3, h = lane >> 5;
+    const uint16_t *at = slab + (16 * s + 8 * h + q) * PITCH + col + 16 * ((lane >> 4) & 1) + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at + 4 * PITCH));
+    return __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 // B operand: 8 contiguous k of one row of up for each of the chunk's two k-steps
 template <int LDT>
@@ -147,14 +166,277 @@ __device__ __forceinline__ void load_up(const uint16_t *up, int rank, int64_t ro
     }
 }
 
-template <int LDT, bool BATCHED>
-__global__ __launch_bounds__(MECHA_BLOCK) void lora_kernel(LoraParams p) {
-    __shared__ __attribute__((aligned(16))) uint16_t lds[2][2][SLAB_HALFS];   // [buffer][slot of the pair]
+// ------------------------------------------------------------------------------------------------ the common case
+// Every network of the key has a rank that is a multiple of 32 and 16-byte aligned factors, cols % 8 == 0 and the key starts
+// 4-element aligned in the arenas (every LoRA the scheduler stages; SDXL / FLUX linear and conv keys).
+// The general path below is bound by latency and instruction issue, not by bytes or flops: it holds one k-chunk of
+// prefetch in registers (231 VGPRs: two waves per SIMD), so every chunk waits out an L2 / HBM round trip, and it spends
+// ~250 VALU + ~170 SALU per chunk on 64-bit addresses, tail guards and the fold against 8 MFMAs (rocprofv3 PMC: 4044
+// VALU and 128 MFMA instructions per wave and tile, MFMA pipe 9 % busy).  Here:
+//   * both factors go global -> LDS with global_load_lds_dwordx4 (no registers) through a ring of RING stages, RING - 1
+//     chunks in flight per block; waves wait with a counted s_waitcnt vmcnt and meet at a raw s_barrier;
+//   * the LDS-DMA writes 64 lanes x 16 B contiguously, so layouts are made on the SOURCE side: the down slab keeps its
+//     256-byte rows with the four 64-byte windows of row k XOR-ed by k & 3 (the transposing reads of 4 consecutive k-rows then
+//     hit 4 different windows: conflict-free), the up slab is [k / 8][row] in 16-byte slots (a lane's B fragment is one
+//     ds_read_b128, 16 consecutive rows per lane group);
+//   * partial tiles read clamped rows / columns (the key's last row, its last 8 columns) instead of guarding every load:
+//     pad, don't mask -- only the base loads and the stores are predicated;
+//   * a network's first k-step starts from C = 0 as an inline constant; the fold is one packed fma per two accumulators
+//     when the scale is a power of two (see below);
+//   * finite checks: base and output through a packed fma(x, 0, poison) (NaN iff some x is inf / NaN), factors (edge tiles
+//     only, read back from the stage) through a packed 16-bit max of the magnitudes.
+typedef uint16_t u16x8v __attribute__((ext_vector_type(8)));
+constexpr int RING = 4;
+constexpr int STAGE_BYTES = 16384;              // down: 32 rows x 256 B, then up: 4 k-parts x 128 rows x 16 B
+constexpr int STAGE_UP = 8192;
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef __attribute__((address_space(1))) const unsigned char global_byte;
+
+__device__ __forceinline__ void glds16(const char *src, unsigned char *dst) {
+    __builtin_amdgcn_global_load_lds((global_byte *)src, (lds_byte *)dst, 16, 0, 0);
+}
+
+template <int LDT>
+__device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_lora_key &key, const mecha_lora_net *nets, int key_index,
+                                               int64_t tile_x, int64_t tile_y, unsigned char *ring) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t bcol0 = tile_x * LORA_TILE, brow0 = tile_y * LORA_TILE;
+    const int wcol = (wave & 1) * 64, wrow = (wave >> 1) * 64;
+    const int64_t row0 = brow0 + wrow + r;
+    const bool check_up = tile_x == 0, check_down = tile_y == 0;
+    const char *base = static_cast<const char *>(p.base);
+    const int64_t last_row = key.rows - 1;
+
+    // ---- LDS-DMA source offsets of this lane (bytes).  Wave-instruction I = 2 * wave + j, j = 0, 1:
+    //   down: fills rows 4I .. 4I+3 of the slab; lane = (row & 3) * 16 + 16-byte slot; slot s of row k holds the logical
+    //         window (s >> 2) ^ (k & 3), i.e. columns 8 * ((((s >> 2) ^ (k & 3)) << 2) | (s & 3)) .. + 7 of the tile;
+    //   up:   fills slots 64I .. 64I+63 of [k-part][row]: k-part = wave, rows 64 j + lane of the tile.
+    const int drow = lane >> 4, dslot = lane & 15;
+    int64_t dcol = bcol0 + 8 * ((((dslot >> 2) ^ drow) << 2) | (dslot & 3));
+    if (dcol > key.cols - 8) dcol = key.cols - 8;
+    const uint32_t d_lane = (uint32_t)(((int64_t)drow * key.cols + dcol) * 2);
+    const uint32_t d_rows4 = (uint32_t)(key.cols * 8);                                      // 4 rows of down
+    uint32_t urow[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) { const int64_t rr = brow0 + 64 * j + lane; urow[j] = (uint32_t)(rr < last_row ? rr : last_row); }
+
+    // ---- LDS read offsets of this lane (bytes inside a stage)
+    const int q = (lane & 15) >> 2, pp = lane & 3, gbit = (lane >> 4) & 1;
+    const int a_lane = (8 * h + q) * 256 + ((16 * gbit + 4 * pp) << 1);                     // + (16 s + 4 f) * 256 + window
+    int a_win[2];
+#pragma unroll
+    for (int cg = 0; cg < 2; cg++) a_win[cg] = ((((wcol >> 5) + cg) ^ q) << 6);
+    const int b_lane = STAGE_UP + (h * 128 + wrow + r) * 16;                                // + (2 s * 128 + 32 rg) * 16
+
+    // ---- the chunk sequence over (network, k0)
+    struct Chunk { int n, k0; bool ok; };
+    int n = 0, k0 = 0;
+    const int n_nets = key.net_count;
+    auto take = [&]() {
+        Chunk c{n, k0, n < n_nets};
+        if (c.ok) { k0 += KC; if (k0 >= nets[n].rank) { k0 = 0; n++; } }
+        return c;
+    };
+    int cur_rank = 0;
+    uint32_t u_lane[2] = {0u, 0u};
+    auto issue = [&](const Chunk &c, int slot) {
+        const mecha_lora_net net = nets[c.n];
+        if (net.rank != cur_rank) {
+            cur_rank = net.rank;
+            u_lane[0] = urow[0] * (uint32_t)net.rank * 2u;
+            u_lane[1] = urow[1] * (uint32_t)net.rank * 2u;
+        }
+        unsigned char *stage = ring + slot * STAGE_BYTES + wave * 2048;
+        const char *dn = static_cast<const char *>(net.down) + (int64_t)(c.k0 + 8 * wave) * key.cols * 2;
+        glds16(dn + d_lane, stage);
+        glds16(dn + d_rows4 + d_lane, stage + 1024);
+        const char *upb = static_cast<const char *>(net.up) + c.k0 * 2 + wave * 16;
+        glds16(upb + u_lane[0], stage + STAGE_UP);
+        glds16(upb + u_lane[1], stage + STAGE_UP + 1024);
+    };
+
+    // prologue: RING - 1 stages in flight, then the base tile
+    Chunk pending[RING];                                                  // pending[i]: the chunk held by slot i
+    int issued = 0;
+#pragma unroll
+    for (int i = 0; i < RING - 1; i++) {
+        pending[i] = take();
+        if (pending[i].ok) { issue(pending[i], i); issued++; }
+    }
+    pending[RING - 1] = Chunk{0, 0, false};
+
+    f32x16 total[2][2];
+    f32x2 poison_in = {0.0f, 0.0f};
+    const f32x2 zero2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+        const int64_t row = row0 + 32 * rg;
+#pragma unroll
+        for (int cg = 0; cg < 2; cg++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t c = bcol0 + wcol + 32 * cg + 8 * g + 4 * h;
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (base != nullptr && row < key.rows && c < key.cols) load4(p.base_dt, true, base, key.offset + row * key.cols + c, 4, v);
+                poison_in = __builtin_elementwise_fma(f32x2{v[0], v[1]}, zero2, poison_in);
+                poison_in = __builtin_elementwise_fma(f32x2{v[2], v[3]}, zero2, poison_in);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) total[rg][cg][g * 4 + q4] = v[q4];
+            }
+        }
+    }
+
+    u16x8v mag = {0, 0, 0, 0, 0, 0, 0, 0};                                                  // running max of |factor| bit patterns (edge tiles)
+    const u16x8v abs_mask = {0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff};
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rg][cg][i] = 0.0f;
+
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    int done = 0;                                                         // chunks consumed so far
+    // one round: wait for the stage in `slot`, refill the slot read in the previous round, multiply
+    auto round = [&](int slot) {
+        const Chunk now = pending[slot];
+        const int later = issued - done - 1;                              // stages issued after this one: 0 .. RING - 2
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const int refill = (slot + RING - 1) % RING;
+            pending[refill] = take();
+            if (pending[refill].ok) { issue(pending[refill], refill); issued++; }
+        }
+        const unsigned char *stage = ring + slot * STAGE_BYTES;
+        u16x8 a[2][2], b[2][2];                                           // [k-step][column group], [k-step][row group]
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+#pragma unroll
+            for (int cg = 0; cg < 2; cg++) {
+                const unsigned char *at = stage + a_lane + a_win[cg] + 16 * s * 256;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at + 4 * 256));
+                a[s][cg] = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++) b[s][rg] = *reinterpret_cast<const u16x8 *>(stage + b_lane + (2 * s * 128 + 32 * rg) * 16);
+        }
+        if (now.k0 == 0) {                                                // a network's first k-step starts from C = 0 (an inline constant: no register clears)
+            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++) {
+                acc[rg][0] = mfma16<LDT>(a[0][0], b[0][rg], zero);
+                acc[rg][1] = mfma16<LDT>(a[0][1], b[0][rg], zero);
+            }
+        } else {
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++) {
+                acc[rg][0] = mfma16<LDT>(a[0][0], b[0][rg], acc[rg][0]);
+                acc[rg][1] = mfma16<LDT>(a[0][1], b[0][rg], acc[rg][1]);
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++) {
+            acc[rg][0] = mfma16<LDT>(a[1][0], b[1][rg], acc[rg][0]);
+            acc[rg][1] = mfma16<LDT>(a[1][1], b[1][rg], acc[rg][1]);
+        }
+        if (check_down) {                                                 // this thread's 32 bytes of the down slab
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + t * 32) & abs_mask);
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + t * 32 + 16) & abs_mask);
+        }
+        if (check_up) {
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + t * 32) & abs_mask);
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + t * 32 + 16) & abs_mask);
+        }
+        const mecha_lora_net net = nets[now.n];
+        if (now.k0 + KC >= net.rank) {                                    // the network is complete: delta * scale, then addcmul
+            const float scale = net.scale, weight = net.weight;
+            // fma(round(acc * scale), weight, total) (lycoris.py:263 then linear.py:76).  With a power-of-two scale (alpha / rank
+            // usually is one) acc * scale and scale * weight are exact, so one fma gives the same bits; two per instruction
+            // (v_pk_fma_f32).  Only results below the normal range could differ, where acc * scale would round and this does not.
+            const uint32_t sb = __float_as_uint(scale), swb = __float_as_uint(scale * weight);
+            const bool one_step = ((sb & 0x007fffffu) == 0u) && (((sb >> 23) & 0xffu) - 1u < 254u) && (((swb >> 23) & 0xffu) - 1u < 254u);
+            if (one_step) {
+                const f32x2 sw = {scale * weight, scale * weight};
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) {
+                            const f32x2 f = __builtin_elementwise_fma(f32x2{acc[rg][cg][i], acc[rg][cg][i + 1]}, sw, f32x2{total[rg][cg][i], total[rg][cg][i + 1]});
+                            total[rg][cg][i] = f.x; total[rg][cg][i + 1] = f.y;
+                        }
+            } else {
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) total[rg][cg][i] = __builtin_fmaf(acc[rg][cg][i] * scale, weight, total[rg][cg][i]);
+            }
+        }
+        done++;
+    };
+    while (true) {
+        if (!pending[0].ok) break;
+        round(0);
+        if (!pending[1].ok) break;
+        round(1);
+        if (!pending[2].ok) break;
+        round(2);
+        if (!pending[3].ok) break;
+        round(3);
+    }
+
+    f32x2 poison_out = {0.0f, 0.0f};
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+        const int64_t row = row0 + 32 * rg;
+#pragma unroll
+        for (int cg = 0; cg < 2; cg++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t c = bcol0 + wcol + 32 * cg + 8 * g + 4 * h;
+                if (row < key.rows && c < key.cols) {
+                    float v[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) v[q4] = total[rg][cg][g * 4 + q4];
+                    poison_out = __builtin_elementwise_fma(f32x2{v[0], v[1]}, zero2, poison_out);
+                    poison_out = __builtin_elementwise_fma(f32x2{v[2], v[3]}, zero2, poison_out);
+                    store4(p.out_dt, true, p.out, key.offset + row * key.cols + c, 4, v);
+                }
+            }
+        }
+    }
+    bool bad_in = (poison_in.x != poison_in.x) || (poison_in.y != poison_in.y);
+    const bool bad_out = (poison_out.x != poison_out.x) || (poison_out.y != poison_out.y);
+    const uint16_t inf_bits = LDT == MECHA_F16 ? 0x7c00 : 0x7f80;
+#pragma unroll
+    for (int j = 0; j < 8; j++) bad_in |= mag[j] >= inf_bits;
+    if ((bad_in | bad_out) && p.flags != nullptr)
+        atomicOr(p.flags + key_index, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+}
+
+// FAST: the kernel of the common case (its tiles only); !FAST: the general path (the other tiles only).  Two kernels rather
+// than one branch: together they do not fit the 256 registers of two waves per SIMD.
+template <int LDT, bool BATCHED, bool FAST>
+__global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FAST ? RING * STAGE_BYTES : 2 * SLAB_HALFS * 2];
+    uint16_t (&lds)[2][SLAB_HALFS] = *reinterpret_cast<uint16_t (*)[2][SLAB_HALFS]>(lds_raw);
     // ---- which key, which tile
+    int64_t tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= tiles_per_xcd || tile >= n_tiles) return;      // whole block
     mecha_lora_key key;
     const mecha_lora_net *nets;
     int key_index = 0;
-    int64_t tile = blockIdx.x;
     if constexpr (BATCHED) {
         int lo = 0, hi = p.n_keys - 1;
         while (lo < hi) {
@@ -169,39 +451,57 @@ __global__ __launch_bounds__(MECHA_BLOCK) void lora_kernel(LoraParams p) {
         key = p.key0;
         nets = p.net0;
     }
-    const int64_t tiles_x = (key.cols + 63) / 64;
+    const int64_t tiles_x = (key.cols + LORA_TILE - 1) / LORA_TILE;
     const int64_t tile_y = tile / tiles_x, tile_x = tile % tiles_x;
+    {
+        bool fast = ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 3) == 0) && key.rows < ((int64_t)1 << 31);
+        for (int i = 0; i < key.net_count && fast; i++) {
+            const mecha_lora_net net = nets[i];
+            fast = ((net.rank & 31) == 0) && (((reinterpret_cast<uintptr_t>(net.up) | reinterpret_cast<uintptr_t>(net.down)) & 15u) == 0) &&
+                   (key.rows * (int64_t)net.rank < ((int64_t)1 << 30));
+        }
+        if (fast != FAST) return;                                         // block-uniform: the other kernel's tile
+    }
+    if constexpr (FAST) {
+        lora_tile_fast<LDT>(p, key, nets, key_index, tile_x, tile_y, lds_raw);
+    } else {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     // transposed product: MFMA rows <-> output columns, MFMA columns <-> output rows
-    const int64_t bcol0 = tile_x * 64;                                    // block's first output column
-    const int wcol = (wave & 1) * 32;                                     // this wave's columns inside the block tile
-    const int64_t out_row = tile_y * 64 + (wave >> 1) * 32 + r;           // D^T column index = lane & 31
-    const bool row_ok = out_row < key.rows;
+    const int64_t bcol0 = tile_x * LORA_TILE;                             // block's first output column
+    const int wcol = (wave & 1) * 64;                                     // this wave's columns inside the block tile
+    const int64_t row0 = tile_y * LORA_TILE + (wave >> 1) * 64 + r;       // this lane's rows: row0 and row0 + 32
     const char *base = static_cast<const char *>(p.base);
-    const int64_t elem0 = key.offset + out_row * key.cols;                // first element of this lane's row in the arenas
     const bool vec4 = ((key.cols & 3) == 0) && ((key.offset & 3) == 0);   // rows start 4-element aligned (arenas are 16-B aligned)
     // every factor element is read by a whole row / column of tiles: the tiles on the key's first column check `up`,
     // those on its first row check `down`, once each
     const bool check_up = tile_x == 0, check_down = tile_y == 0;
 
-    // total starts at the base value (fp32).  D^T layout: reg g*4+q holds output column bcol0 + wcol + 8g + 4h + q of out_row.
-    f32x16 total;
+    // total starts at the base value (fp32).  D^T layout of tile (rg, cg): reg g*4+q holds output column
+    // bcol0 + wcol + 32 cg + 8g + 4h + q of row row0 + 32 rg.
+    f32x16 total[2][2];
     bool bad_in = false;
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int64_t c = bcol0 + wcol + 8 * g + 4 * h;
-        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (base != nullptr && row_ok && c < key.cols) {
-            const int valid = key.cols - c >= 4 ? 4 : (int)(key.cols - c);
-            load4(p.base_dt, vec4 && valid == 4, base, elem0 + c, valid, v);
-        }
+    for (int rg = 0; rg < 2; rg++) {
+        const int64_t row = row0 + 32 * rg;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { bad_in |= nonfinite_f32(v[q]); total[g * 4 + q] = v[q]; }
+        for (int cg = 0; cg < 2; cg++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int64_t c = bcol0 + wcol + 32 * cg + 8 * g + 4 * h;
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (base != nullptr && row < key.rows && c < key.cols) {
+                    const int valid = key.cols - c >= 4 ? 4 : (int)(key.cols - c);
+                    load4(p.base_dt, vec4 && valid == 4, base, key.offset + row * key.cols + c, valid, v);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { bad_in |= nonfinite_f32(v[q]); total[rg][cg][g * 4 + q] = v[q]; }
+            }
+        }
     }
 
-    // ---- the chunk sequence over (network, k0), two chunks per round: the next pair's global loads are in flight while
-    // the current pair is multiplied; one barrier per pair (double-buffered LDS)
+    // ---- the chunk sequence over (network, k0): the next chunk's global loads are in flight while the current one is
+    // multiplied; one barrier per chunk (double-buffered LDS)
     struct Chunk { int n, k0; bool ok; };
     int n = 0, k0 = 0;
     const int n_nets = key.net_count;
@@ -210,48 +510,86 @@ __global__ __launch_bounds__(MECHA_BLOCK) void lora_kernel(LoraParams p) {
         if (c.ok) { k0 += KC; if (k0 >= nets[n].rank) { k0 = 0; n++; } }
         return c;
     };
-    u16x8 dv[2], bv[2][2];
-    auto fetch = [&](const Chunk &c, int slot) {
+    u16x8 dv[2], bv[2][2];                                                // down: two k-rows; up: [row group][k-step]
+    auto fetch = [&](const Chunk &c) {
         if (!c.ok) return;
         const mecha_lora_net net = nets[c.n];
         const uint16_t *down = static_cast<const uint16_t *>(net.down), *up = static_cast<const uint16_t *>(net.up);
-        dv[slot] = load_down<LDT>(down, net.rank, key.cols, bcol0, c.k0, ((key.cols & 7) == 0) && ((reinterpret_cast<uintptr_t>(down) & 15u) == 0), check_down, bad_in);
-        load_up<LDT>(up, net.rank, out_row, row_ok, c.k0, h, ((net.rank & 7) == 0) && ((reinterpret_cast<uintptr_t>(up) & 15u) == 0), check_up, bv[slot], bad_in);
-    };
-    Chunk next[2] = {take(), take()};
-    fetch(next[0], 0);
-    fetch(next[1], 1);
-    f32x16 acc;
+        load_down<LDT>(down, net.rank, key.cols, bcol0, c.k0, ((key.cols & 7) == 0) && ((reinterpret_cast<uintptr_t>(down) & 15u) == 0), check_down, dv, bad_in);
+        const bool up_vec = ((net.rank & 7) == 0) && ((reinterpret_cast<uintptr_t>(up) & 15u) == 0);
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+        for (int rg = 0; rg < 2; rg++) load_up<LDT>(up, net.rank, row0 + 32 * rg, row0 + 32 * rg < key.rows, c.k0, h, up_vec, check_up, bv[rg], bad_in);
+    };
+    Chunk next = take();
+    fetch(next);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rg][cg][i] = 0.0f;
     int buf = 0;
-    while (next[0].ok) {
-        const Chunk now[2] = {next[0], next[1]};
+    while (next.ok) {
+        const Chunk now = next;
+        stage_down(lds[buf], dv);
         u16x8 b_now[2][2];
 #pragma unroll
-        for (int slot = 0; slot < 2; slot++) {
-            if (now[slot].ok) stage_down(lds[buf][slot], dv[slot]);
-            b_now[slot][0] = bv[slot][0]; b_now[slot][1] = bv[slot][1];
-        }
-        next[0] = take(); next[1] = take();
-        fetch(next[0], 0);
-        fetch(next[1], 1);
-        __syncthreads();                                                  // pair `buf` is complete; the other buffer's readers are done (barrier of the previous round)
+        for (int rg = 0; rg < 2; rg++) { b_now[rg][0] = bv[rg][0]; b_now[rg][1] = bv[rg][1]; }
+        next = take();
+        fetch(next);
+        __syncthreads();                                                  // slab `buf` is complete; the other buffer's readers are done (barrier of the previous round)
+        const int rank = nets[now.n].rank;
+        {
+            const u16x8 a0 = read_a(lds[buf], 0, wcol), a1 = read_a(lds[buf], 0, wcol + 32);
+            if (now.k0 == 0) {                                            // a network's first k-step starts from C = 0 (an inline constant: no register clears)
+                const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int slot = 0; slot < 2; slot++) {
-            if (!now[slot].ok) continue;
-            const int rank = nets[now[slot].n].rank;
+                for (int rg = 0; rg < 2; rg++) {
+                    acc[rg][0] = mfma16<LDT>(a0, b_now[rg][0], zero);
+                    acc[rg][1] = mfma16<LDT>(a1, b_now[rg][0], zero);
+                }
+            } else {
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                if (now[slot].k0 + 16 * s < rank) {
-                    const u16x8 a = *reinterpret_cast<const u16x8 *>(&lds[buf][slot][slab_index(16 * s + 8 * h, wcol + r)]);
-                    acc = mfma16<LDT>(a, b_now[slot][s], acc);
+                for (int rg = 0; rg < 2; rg++) {
+                    acc[rg][0] = mfma16<LDT>(a0, b_now[rg][0], acc[rg][0]);
+                    acc[rg][1] = mfma16<LDT>(a1, b_now[rg][0], acc[rg][1]);
                 }
             }
-            if (now[slot].k0 + KC >= rank) {                              // the network is complete: delta * scale, then addcmul
-                const float scale = nets[now[slot].n].scale, weight = nets[now[slot].n].weight;
+        }
+        if (now.k0 + 16 < rank) {
+            const u16x8 a0 = read_a(lds[buf], 1, wcol), a1 = read_a(lds[buf], 1, wcol + 32);
 #pragma unroll
-                for (int i = 0; i < 16; i++) { total[i] = __builtin_fmaf(acc[i] * scale, weight, total[i]); acc[i] = 0.0f; }
+            for (int rg = 0; rg < 2; rg++) {
+                acc[rg][0] = mfma16<LDT>(a0, b_now[rg][1], acc[rg][0]);
+                acc[rg][1] = mfma16<LDT>(a1, b_now[rg][1], acc[rg][1]);
+            }
+        }
+        if (now.k0 + KC >= rank) {                                        // the network is complete: delta * scale, then addcmul
+            const float scale = nets[now.n].scale, weight = nets[now.n].weight;
+            // fma(round(acc * scale), weight, total) (lycoris.py:263 then linear.py:76).  With a power-of-two scale (alpha / rank
+            // usually is one) acc * scale and scale * weight are exact, so one fma gives the same bits; two per instruction
+            // (v_pk_fma_f32).  Only results below the normal range could differ, where acc * scale would round and this does not.
+            const uint32_t sb = __float_as_uint(scale), swb = __float_as_uint(scale * weight);
+            const bool one_step = ((sb & 0x007fffffu) == 0u) && (((sb >> 23) & 0xffu) - 1u < 254u) && (((swb >> 23) & 0xffu) - 1u < 254u);
+            if (one_step) {
+                const f32x2 sw = {scale * weight, scale * weight};
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) {
+                            const f32x2 t = __builtin_elementwise_fma(f32x2{acc[rg][cg][i], acc[rg][cg][i + 1]}, sw, f32x2{total[rg][cg][i], total[rg][cg][i + 1]});
+                            total[rg][cg][i] = t.x; total[rg][cg][i + 1] = t.y;
+                        }
+            } else {
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) total[rg][cg][i] = __builtin_fmaf(acc[rg][cg][i] * scale, weight, total[rg][cg][i]);
             }
         }
         buf ^= 1;
@@ -259,20 +597,47 @@ __global__ __launch_bounds__(MECHA_BLOCK) void lora_kernel(LoraParams p) {
 
     bool bad_out = false;
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int64_t c = bcol0 + wcol + 8 * g + 4 * h;
-        if (row_ok && c < key.cols) {
-            float v[4];
+    for (int rg = 0; rg < 2; rg++) {
+        const int64_t row = row0 + 32 * rg;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { v[q] = total[g * 4 + q]; }
-            const int valid = key.cols - c >= 4 ? 4 : (int)(key.cols - c);
+        for (int cg = 0; cg < 2; cg++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) bad_out |= (q < valid) && nonfinite_f32(v[q]);
-            store4(p.out_dt, vec4 && valid == 4, p.out, elem0 + c, valid, v);
+            for (int g = 0; g < 4; g++) {
+                const int64_t c = bcol0 + wcol + 32 * cg + 8 * g + 4 * h;
+                if (row < key.rows && c < key.cols) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { v[q] = total[rg][cg][g * 4 + q]; }
+                    const int valid = key.cols - c >= 4 ? 4 : (int)(key.cols - c);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) bad_out |= (q < valid) && nonfinite_f32(v[q]);
+                    store4(p.out_dt, vec4 && valid == 4, p.out, key.offset + row * key.cols + c, valid, v);
+                }
+            }
         }
     }
     if ((bad_in | bad_out) && p.flags != nullptr)
         atomicOr(p.flags + key_index, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+    }
+}
+
+// the host's copy of the kernel's test, for the launch decision
+bool net_is_fast(const mecha_lora_net &net, int64_t rows) {
+    return ((net.rank & 31) == 0) && (((reinterpret_cast<uintptr_t>(net.up) | reinterpret_cast<uintptr_t>(net.down)) & 15u) == 0) &&
+           (rows * (int64_t)net.rank < ((int64_t)1 << 30));
+}
+bool key_is_fast(const mecha_lora_key &key) {
+    return ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 3) == 0) && key.rows < ((int64_t)1 << 31);
+}
+
+template <int LDT, bool BATCHED>
+int launch_lora(const LoraParams &p, int64_t tiles, bool any_fast, bool any_general, hipStream_t s) {
+    MECHA_REQUIRE(tiles + 8 <= 0x7fffffff, "grid too large");
+    const int64_t per_xcd = (tiles + 7) / 8;
+    if (any_fast) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, true>), dim3((unsigned)(per_xcd * 8)), dim3(MECHA_BLOCK), 0, s, p, tiles, per_xcd);
+    if (any_general) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, false>), dim3((unsigned)(per_xcd * 8)), dim3(MECHA_BLOCK), 0, s, p, tiles, per_xcd);
+    MECHA_CHECK_HIP(hipGetLastError());
+    return MECHA_OK;
 }
 
 int check_common(const void *out, int base_dtype, int out_dtype, int lora_dtype, const void *base) {
@@ -308,39 +673,41 @@ int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t col
     }
     p.key0 = mecha_lora_key{0, rows, cols, 0, 0, n};
     p.n_keys = 1;
-    const int64_t tiles = ((cols + 63) / 64) * ((rows + 63) / 64);
-    MECHA_REQUIRE(tiles <= 0x7fffffff, "grid too large");
+    const int64_t tiles = ((cols + LORA_TILE - 1) / LORA_TILE) * ((rows + LORA_TILE - 1) / LORA_TILE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (lora_dtype == MECHA_F16) MECHA_LAUNCH(MK_LORA, (lora_kernel<MECHA_F16, false>), dim3((unsigned)tiles), dim3(MECHA_BLOCK), 0, s, p);
-    else MECHA_LAUNCH(MK_LORA, (lora_kernel<MECHA_BF16, false>), dim3((unsigned)tiles), dim3(MECHA_BLOCK), 0, s, p);
-    MECHA_CHECK_HIP(hipGetLastError());
-    return MECHA_OK;
+    bool fast = key_is_fast(p.key0);
+    for (int i = 0; i < n && fast; i++) fast = net_is_fast(p.net0[i], rows);
+    return lora_dtype == MECHA_F16 ? launch_lora<MECHA_F16, false>(p, tiles, fast, !fast, s) : launch_lora<MECHA_BF16, false>(p, tiles, fast, !fast, s);
 }
 
 int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const mecha_lora_key *keys, const mecha_lora_key *keys_host,
-                                  int n_keys, const mecha_lora_net *nets, int base_dtype, int out_dtype, int lora_dtype,
-                                  uint32_t *key_flags, void *stream) {
+                                  int n_keys, const mecha_lora_net *nets, const mecha_lora_net *nets_host, int base_dtype, int out_dtype,
+                                  int lora_dtype, uint32_t *key_flags, void *stream) {
     MECHA_REQUIRE(n_keys >= 0, "n_keys must be >= 0");
     if (n_keys == 0) return MECHA_OK;
     if (int e = check_common(out_arena, base_dtype, out_dtype, lora_dtype, base_arena)) return e;
     MECHA_REQUIRE(keys != nullptr && keys_host != nullptr && nets != nullptr, "NULL key / network table");
     int64_t tiles = 0;
+    bool any_fast = nets_host == nullptr, any_general = nets_host == nullptr;     // without the host copy both kernels run
     for (int i = 0; i < n_keys; i++) {
         const mecha_lora_key &k = keys_host[i];
+        if (nets_host != nullptr) {
+            bool fast = key_is_fast(k);
+            for (int j = 0; j < k.net_count && fast && k.net_begin >= 0; j++) fast = net_is_fast(nets_host[k.net_begin + j], k.rows);
+            any_fast |= fast; any_general |= !fast;
+        }
         MECHA_REQUIRE(k.rows >= 1 && k.cols >= 1 && k.offset >= 0 && k.net_begin >= 0 && k.net_count >= 0 && k.net_count <= LORA_MAX_NETS,
                       "key %d: bad shape, offset or network range", i);
-        MECHA_REQUIRE(k.tile_start == tiles, "key %d: tile_start must be the running sum of ceil(rows/64) * ceil(cols/64) (expected %lld)", i, (long long)tiles);
-        tiles += ((k.cols + 63) / 64) * ((k.rows + 63) / 64);
+        MECHA_REQUIRE(k.tile_start == tiles, "key %d: tile_start must be the running sum of ceil(rows/%d) * ceil(cols/%d) (expected %lld)", i,
+                      LORA_TILE, LORA_TILE, (long long)tiles);
+        tiles += ((k.cols + LORA_TILE - 1) / LORA_TILE) * ((k.rows + LORA_TILE - 1) / LORA_TILE);
     }
-    MECHA_REQUIRE(tiles <= 0x7fffffff, "grid too large");
     LoraParams p{};
     p.base = base_arena; p.out = out_arena; p.base_dt = base_dtype; p.out_dt = out_dtype; p.flags = key_flags;
     p.keys = keys; p.nets = nets; p.n_keys = n_keys;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (lora_dtype == MECHA_F16) MECHA_LAUNCH(MK_LORA, (lora_kernel<MECHA_F16, true>), dim3((unsigned)tiles), dim3(MECHA_BLOCK), 0, s, p);
-    else MECHA_LAUNCH(MK_LORA, (lora_kernel<MECHA_BF16, true>), dim3((unsigned)tiles), dim3(MECHA_BLOCK), 0, s, p);
-    MECHA_CHECK_HIP(hipGetLastError());
-    return MECHA_OK;
+    return lora_dtype == MECHA_F16 ? launch_lora<MECHA_F16, true>(p, tiles, any_fast, any_general, s)
+                                   : launch_lora<MECHA_BF16, true>(p, tiles, any_fast, any_general, s);
 }
 
 }  // extern "C"

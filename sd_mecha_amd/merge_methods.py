@@ -493,10 +493,10 @@ class LoraBatch:
             if len(nets) - begin > _lib.MAX_MODELS:
                 raise ValueError(f"at most {_lib.MAX_MODELS} networks per key")
             keys.append(_lib.LoraKey(int(offset), int(rows), int(cols), tile, begin, len(nets) - begin))
-            tile += ((cols + 63) // 64) * ((rows + 63) // 64)
+            tile += ((cols + _lib.LORA_TILE - 1) // _lib.LORA_TILE) * ((rows + _lib.LORA_TILE - 1) // _lib.LORA_TILE)
         self.n_keys = len(keys)
         self.keys_host = (_lib.LoraKey * max(len(keys), 1))(*keys)
-        nets_host = (_lib.LoraNet * max(len(nets), 1))(*nets)
+        self.nets_host = nets_host = (_lib.LoraNet * max(len(nets), 1))(*nets)
         self.keys_dev = torch.frombuffer(bytearray(bytes(self.keys_host)), dtype=torch.uint8).to(device)
         self.nets_dev = torch.frombuffer(bytearray(bytes(nets_host)), dtype=torch.uint8).to(device)
 
@@ -505,7 +505,7 @@ class LoraBatch:
             return
         _lib.check(_lib.lib().mecha_batched_lora_accumulate(
             base_arena.data_ptr() if base_arena is not None else None, out_arena.data_ptr(), self.keys_dev.data_ptr(),
-            ctypes.addressof(self.keys_host), self.n_keys, self.nets_dev.data_ptr(),
+            ctypes.addressof(self.keys_host), self.n_keys, self.nets_dev.data_ptr(), ctypes.addressof(self.nets_host),
             _DT[base_arena.dtype] if base_arena is not None else F32, _DT[out_arena.dtype], _DT[self.lora_dtype or torch.float16],
             key_flags.data_ptr() if key_flags is not None else None, _stream()), "mecha_batched_lora_accumulate")
 

@@ -36,6 +36,7 @@ import torch
 from . import _lib
 from . import lora as lora_mod
 from . import merge_methods as mm
+from . import model_configs
 from .arena import ArenaLayout, plan_arena, shard_keys_lpt
 from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError
 from .recipe_nodes import LiteralRecipeNode, MergeRecipeNode, ModelRecipeNode, RecipeNode, serialize, value_to_node
@@ -376,13 +377,23 @@ def merge(
         merge_inputs = plan.models if plan is not None else [m for m in models if id(m) not in aux]
         if not merge_inputs:
             raise ValueError("the recipe has no model inputs besides LoRA files")
+        # model config: explicit (model(path, config=...)) or inferred from the key names (graph_finalization.py:1024-1058,
+        # :591-624, :698); no candidate = the structural config, the keys every input holds with one shape (:695-696)
+        config = model_configs.infer([readers[id(m)].keys() for m in merge_inputs], [getattr(m, "config", None) for m in merge_inputs])
+        if config is not None:
+            for m in merge_inputs:                                           # inputs may name a key by an alias (merging.py:394-403)
+                readers[id(m)].apply_aliases(config.resolve_alias)
         first = readers[id(merge_inputs[0])]
         items, header = [], {}
-        for key, meta in first.metadata():
+        for key in (config.keys() if config is not None else first.keys()):
+            if key not in first:
+                continue                                                     # StateDictKeyError -> the key is skipped (merging.py:312-316)
+            meta = first.meta(key)
             ok = all(key in readers[id(m)] and readers[id(m)].meta(key).shape == meta.shape for m in merge_inputs)
             if ok:
                 items.append((key, meta.numel()))
                 header[key] = TensorMetadata(meta.shape, output_dtype)
+        log.debug("model config: %s, %d keys", config.identifier if config is not None else "structural", len(items))
         my_items = shard_keys_lpt(items, world)[rank] if world > 1 else items
         order = {k: i for i, (k, _) in enumerate(items)}
         my_items.sort(key=lambda kv: order[kv[0]])

@@ -38,8 +38,9 @@ class RecipeNode:
 class ModelRecipeNode(RecipeNode):
     """A checkpoint on disk (helpers.py:15-43 ``sd_mecha.model(path)``)."""
 
-    def __init__(self, path):
+    def __init__(self, path, config=None):
         self.path = pathlib.Path(path)
+        self.config = config                  # model config identifier, or None: inferred from the key names at merge time
 
     def __repr__(self):
         return f"model({str(self.path)!r})"
@@ -74,8 +75,9 @@ def value_to_node(v) -> RecipeNode:
     return LiteralRecipeNode(v)
 
 
-def model(path) -> ModelRecipeNode:
-    return ModelRecipeNode(path)
+def model(path, config=None) -> ModelRecipeNode:
+    """helpers.py:15-43: ``config`` is a model config identifier ("sdxl-sgm", ...) or None to infer it."""
+    return ModelRecipeNode(path, config)
 
 
 def literal(value) -> LiteralRecipeNode:

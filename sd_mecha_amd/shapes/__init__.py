@@ -26,7 +26,7 @@ def load_manifest(identifier: str, components: Optional[Sequence[str]] = None) -
     for cname, keys in doc["components"].items():
         if components is not None and cname not in components:
             continue
-        for key, shape, dtype, _optional in keys:
+        for key, shape, dtype, *_rest in keys:            # [key, shape, dtype, optional, aliases]
             if shape is None:
                 continue
             out.append((key, tuple(int(s) for s in shape), dtype))

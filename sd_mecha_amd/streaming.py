@@ -98,6 +98,17 @@ class InSafetensorsDict(Mapping):
             for k, v in self.header.items() if k != "__metadata__"
         }
 
+    def apply_aliases(self, resolve) -> None:
+        """Re-key the tensors by their canonical names (``resolve``: alias -> key of the model config, identity for
+        anything else).  The reference looks an output key up under its own name first, then under its aliases
+        (merging.py:394-403): a file that holds both keeps the canonical entry."""
+        renamed = {k: v for k, v in self._meta.items() if resolve(k) == k}
+        for k, v in self._meta.items():
+            canon = resolve(k)
+            if canon != k and canon not in renamed:
+                renamed[canon] = v
+        self._meta = renamed
+
     # ---- mapping protocol
     def __contains__(self, key):
         return key in self._meta

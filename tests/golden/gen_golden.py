@@ -325,11 +325,54 @@ def gen_e2e_lora(out):
     out["shapes_keys"] = np.array(list(shapes.keys()))
 
 
+def gen_configs(out):
+    """Config auto-detection (graph_finalization.py:1024-1058): for several key sets, the reference's candidate statistics
+    of the four configs this repo ships and the config it would pick among them."""
+    from sd_mecha import graph_finalization as gf
+    from sd_mecha.extensions import model_configs
+    shipped = ["sd1-ldm", "sdxl-sgm", "sdxl-kohya", "flux-flux"]
+    rng = np.random.default_rng(11)
+
+    def keys_of(ident, components=None, alias=False):
+        cfg = model_configs.resolve(ident)
+        ks = []
+        for cname, comp in cfg.components().items():
+            if components is not None and cname not in components:
+                continue
+            for k, m in comp.keys().items():
+                ks.append(m.aliases[0] if alias and m.aliases else k)
+        return ks
+
+    cases = {
+        "sdxl_full": keys_of("sdxl-sgm"),
+        "sdxl_kohya_full": keys_of("sdxl-kohya"),
+        "sd1_no_ema": keys_of("sd1-ldm", ("clip_l", "vae", "diffuser", "scheduler")),
+        "sd1_aliases": keys_of("sd1-ldm", alias=True),
+        "flux_diffuser_aliases": keys_of("flux-flux", ("diffuser",), alias=True),
+        "flux_full": keys_of("flux-flux"),
+        "sdxl_plus_junk": keys_of("sdxl-sgm") + [f"junk.{i}" for i in range(400)],
+        "sdxl_vae_only": keys_of("sdxl-sgm", ("vae",)),
+        "unknown": [f"layer.{i}.weight" for i in range(50)],
+        "sdxl_tenth": [k for k in keys_of("sdxl-sgm") if rng.random() < 0.1] + [f"junk.{i}" for i in range(100)],
+    }
+    out["case_names"] = np.array(list(cases))
+    out["shipped"] = np.array(shipped)
+    for name, ks in cases.items():
+        out[f"{name}_keys"] = np.array(ks)
+        stats = gf.generate_configs_stats(ks)
+        cand = [c for c in shipped if c in stats]
+        out[f"{name}_candidates"] = np.array(cand, dtype="U32")
+        out[f"{name}_stats"] = np.array([[len(stats[c].intersection), stats[c].state_dict_misses, stats[c].config_misses] for c in cand], dtype=np.float64).reshape(len(cand), 3)
+        best = min(((c, stats[c]) for c in cand), key=lambda kv: kv[1].state_dict_misses)[0] if cand else ""
+        out[f"{name}_best"] = np.array(best)
+
+
 def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
     only = set(sys.argv[1:])
     for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare),
-                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_lora", gen_e2e_lora)]:
+                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_lora", gen_e2e_lora),
+                     ("configs", gen_configs)]:
         if only and name not in only:
             continue
         out = {}

@@ -125,3 +125,44 @@ def test_lora_conv_shapes_and_validation():
     bad[3, 2] = float("nan")
     with pytest.raises(amd.NonFiniteStateDictKeyError):
         amd.lora_merge(base, [(bad, down, 4.0, 1.0)], key="k")
+
+
+@pytest.mark.parametrize("ldt", ["float16", "bfloat16"])
+def test_lora_fast_kernel_edges(oracle, ldt):
+    """The LDS-DMA kernel (every rank a multiple of 32, cols % 8 == 0): partial tiles in both directions (clamped loads),
+    ranks that differ between networks, a scale that is not a power of two (two-step fold), fp32 / fp16 base and output,
+    and the finite checks of factors on edge tiles."""
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(5)
+    for rows, cols, ranks, bdt in [(200, 136, [32, 64, 32], "bfloat16"), (129, 8, [32], "float16"), (72, 1000, [96, 32], "bfloat16"),
+                                   (384, 264, [32] * 5, "float16")]:
+        base_b = oracle.from_f32(rng.normal(0, 0.02, size=(rows, cols)).astype(np.float32), bdt)
+        acc = oracle.to_f32(base_b, bdt)
+        mag = np.abs(acc)
+        nets = []
+        for i, r in enumerate(ranks):
+            up_b = oracle.from_f32(rng.normal(0, 0.05, size=(rows, r)).astype(np.float32), ldt)
+            down_b = oracle.from_f32(rng.normal(0, 0.05, size=(r, cols)).astype(np.float32), ldt)
+            alpha, w = (float(r) / 2, 0.6) if i % 2 == 0 else (7.0, 1.0)          # scale 0.5, or 7 / r (not a power of two)
+            delta = oracle.lora_delta(oracle.to_f32(up_b, ldt), oracle.to_f32(down_b, ldt), alpha)
+            acc = oracle.add_difference(acc, delta, w)
+            mag = mag + np.abs(delta)
+            nets.append((dev16(up_b, ldt), dev16(down_b, ldt), alpha, w))
+        tbase = dev16(base_b, bdt).reshape(rows, cols)
+        got = amd.lora_merge(tbase, nets, out_dtype=TDT[bdt])
+        d = ulp_distance_half(bits16(got), oracle.from_f32(acc, bdt)) if bdt == "bfloat16" else None
+        if d is not None:
+            noise = np.abs(got.float().cpu().numpy() - acc) <= 1e-6 * mag
+            assert ((d <= 1) | noise).all() and (d > 0).mean() < 0.005, (rows, cols, d.max(), (d > 0).mean())
+        else:
+            assert np.allclose(got.float().cpu().numpy(), acc, rtol=2e-3, atol=1e-6)
+        got32 = amd.lora_merge(tbase.float(), nets).cpu().numpy()                # fp32 base and output
+        assert np.allclose(got32, acc, rtol=2e-5, atol=1e-7)
+        # a non-finite factor anywhere flags the key; the last row / last column sit in partial tiles
+        for which, (i, j) in (("up", (rows - 1, ranks[0] - 1)), ("down", (ranks[0] - 1, cols - 1)), ("up", (0, 0)), ("down", (0, 0))):
+            bad = [list(nw) for nw in nets]
+            tgt = bad[0][0 if which == "up" else 1].clone()
+            tgt[i, j] = float("inf")
+            bad[0][0 if which == "up" else 1] = tgt
+            with pytest.raises(amd.NonFiniteStateDictKeyError):
+                amd.lora_merge(tbase, [tuple(nw) for nw in bad], out_dtype=TDT[bdt], key="k")

@@ -33,11 +33,11 @@ for ident in ("sd1-ldm", "sdxl-sgm", "flux-flux", "sdxl-kohya"):
     for cname, comp in cfg.components().items():
         comps[cname] = [
             [k, list(m.shape) if m.shape is not None else None, str(m.dtype).replace("torch.", "") if m.dtype is not None else None,
-             bool(m.optional)]
+             bool(m.optional), list(m.aliases)]
             for k, m in comp.keys().items()
         ]
     n_keys = sum(len(v) for v in comps.values())
-    n_params = sum(int(__import__("math").prod(s)) for v in comps.values() for _, s, _, _ in v if s is not None)
+    n_params = sum(int(__import__("math").prod(e[1])) for v in comps.values() for e in v if e[1] is not None)
     doc = {"identifier": ident, "n_keys": n_keys, "n_params": n_params, "components": comps}
     path = OUT / f"{ident}.json.gz"
     with gzip.GzipFile(path, "wb", mtime=0) as f:
