@@ -187,13 +187,20 @@ __device__ __forceinline__ void load_up(const uint16_t *up, int rank, int64_t ro
 //     only, read back from the stage) through a packed 16-bit max of the magnitudes.
 typedef uint16_t u16x8v __attribute__((ext_vector_type(8)));
 constexpr int RING = 4;
+enum : int { NET_STARTS_GROUP = 1, NET_ENDS_GROUP = 2, NET_ONE_STEP = 4 };   // mecha_lora_net::reserved of the LDS copy
 constexpr int STAGE_BYTES = 16384;              // down: 32 rows x 256 B, then up: 4 k-parts x 128 rows x 16 B
 constexpr int STAGE_UP = 8192;
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef __attribute__((address_space(1))) const unsigned char global_byte;
 
+// One LDS-DMA instruction: lane l's 16 bytes at `src` go to dst + 16 l (dst wave-uniform, in M0).  Written as inline
+// assembly on purpose: for the builtin the compiler cannot tell which LDS bytes the DMA writes, so it puts s_waitcnt vmcnt(0)
+// in front of every later LDS read -- that drains the ring in every round (measured: 20.6 ms for the SDXL x16 batch, each
+// round one full L2 / HBM round trip).  Here the waits are the counted s_waitcnt vmcnt of the round itself; loads the
+// compiler does not know about only make its own waits conservative (vmcnt retires in order).
 __device__ __forceinline__ void glds16(const char *src, unsigned char *dst) {
-    __builtin_amdgcn_global_load_lds((global_byte *)src, (lds_byte *)dst, 16, 0, 0);
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte *)dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds), "v"(src) : "memory", "m0");
 }
 
 template <int LDT>
@@ -203,31 +210,27 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int64_t bcol0 = tile_x * LORA_TILE, brow0 = tile_y * LORA_TILE;
-    const int wcol = (wave & 1) * 64, wrow = (wave >> 1) * 64;
+    const int wcol = (wave & 3) * 32, wrow = (wave >> 2) * 64;       // wave tile: 32 columns x 64 rows (8 waves per block)
     const int64_t row0 = brow0 + wrow + r;
     const bool check_up = tile_x == 0, check_down = tile_y == 0;
     const char *base = static_cast<const char *>(p.base);
     const int64_t last_row = key.rows - 1;
 
-    // ---- LDS-DMA source offsets of this lane (bytes).  Wave-instruction I = 2 * wave + j, j = 0, 1:
-    //   down: fills rows 4I .. 4I+3 of the slab; lane = (row & 3) * 16 + 16-byte slot; slot s of row k holds the logical
+    // ---- LDS-DMA source offsets of this lane (bytes).  Each wave issues one 1-KiB instruction per factor and chunk:
+    //   down: wave I fills rows 4I .. 4I+3 of the slab; lane = (row & 3) * 16 + 16-byte slot; slot s of row k holds the logical
     //         window (s >> 2) ^ (k & 3), i.e. columns 8 * ((((s >> 2) ^ (k & 3)) << 2) | (s & 3)) .. + 7 of the tile;
-    //   up:   fills slots 64I .. 64I+63 of [k-part][row]: k-part = wave, rows 64 j + lane of the tile.
+    //   up:   wave I fills slots 64I .. 64I+63 of [k-part][row]: k-part = I >> 1, rows 64 (I & 1) + lane of the tile.
     const int drow = lane >> 4, dslot = lane & 15;
     int64_t dcol = bcol0 + 8 * ((((dslot >> 2) ^ drow) << 2) | (dslot & 3));
     if (dcol > key.cols - 8) dcol = key.cols - 8;
     const uint32_t d_lane = (uint32_t)(((int64_t)drow * key.cols + dcol) * 2);
-    const uint32_t d_rows4 = (uint32_t)(key.cols * 8);                                      // 4 rows of down
-    uint32_t urow[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) { const int64_t rr = brow0 + 64 * j + lane; urow[j] = (uint32_t)(rr < last_row ? rr : last_row); }
+    uint32_t urow;
+    { const int64_t rr = brow0 + 64 * (wave & 1) + lane; urow = (uint32_t)(rr < last_row ? rr : last_row); }
 
     // ---- LDS read offsets of this lane (bytes inside a stage)
     const int q = (lane & 15) >> 2, pp = lane & 3, gbit = (lane >> 4) & 1;
     const int a_lane = (8 * h + q) * 256 + ((16 * gbit + 4 * pp) << 1);                     // + (16 s + 4 f) * 256 + window
-    int a_win[2];
-#pragma unroll
-    for (int cg = 0; cg < 2; cg++) a_win[cg] = ((((wcol >> 5) + cg) ^ q) << 6);
+    const int a_win = (((wcol >> 5) ^ q) << 6);
     const int b_lane = STAGE_UP + (h * 128 + wrow + r) * 16;                                // + (2 s * 128 + 32 rg) * 16
 
     // ---- the chunk sequence over (network, k0)
@@ -240,21 +243,18 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
         return c;
     };
     int cur_rank = 0;
-    uint32_t u_lane[2] = {0u, 0u};
+    uint32_t u_lane = 0u;
     auto issue = [&](const Chunk &c, int slot) {
         const mecha_lora_net net = nets[c.n];
         if (net.rank != cur_rank) {
             cur_rank = net.rank;
-            u_lane[0] = urow[0] * (uint32_t)net.rank * 2u;
-            u_lane[1] = urow[1] * (uint32_t)net.rank * 2u;
+            u_lane = urow * (uint32_t)net.rank * 2u;
         }
-        unsigned char *stage = ring + slot * STAGE_BYTES + wave * 2048;
-        const char *dn = static_cast<const char *>(net.down) + (int64_t)(c.k0 + 8 * wave) * key.cols * 2;
+        unsigned char *stage = ring + slot * STAGE_BYTES + wave * 1024;
+        const char *dn = static_cast<const char *>(net.down) + (int64_t)(c.k0 + 4 * wave) * key.cols * 2;
         glds16(dn + d_lane, stage);
-        glds16(dn + d_rows4 + d_lane, stage + 1024);
-        const char *upb = static_cast<const char *>(net.up) + c.k0 * 2 + wave * 16;
-        glds16(upb + u_lane[0], stage + STAGE_UP);
-        glds16(upb + u_lane[1], stage + STAGE_UP + 1024);
+        const char *upb = static_cast<const char *>(net.up) + c.k0 * 2 + (wave >> 1) * 16;
+        glds16(upb + u_lane, stage + STAGE_UP);
     };
 
     // prologue: RING - 1 stages in flight, then the base tile
@@ -267,36 +267,67 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     }
     pending[RING - 1] = Chunk{0, 0, false};
 
-    f32x16 total[2][2];
+    // ---- the base tile: every load is issued before the first one is consumed, no branch between them.  Rows / columns
+    // past the key's edge read clamped addresses (the key's last row, its last 4 columns) and are zeroed afterwards.
+    f32x16 total[2];
     f32x2 poison_in = {0.0f, 0.0f};
     const f32x2 zero2 = {0.0f, 0.0f};
+    bool in_row[2], in_col[4];
+    int64_t at[2][4];
 #pragma unroll
     for (int rg = 0; rg < 2; rg++) {
         const int64_t row = row0 + 32 * rg;
+        in_row[rg] = row < key.rows;
 #pragma unroll
-        for (int cg = 0; cg < 2; cg++) {
+        for (int g = 0; g < 4; g++) {
+            const int64_t c = bcol0 + wcol + 8 * g + 4 * h;
+            in_col[g] = c < key.cols;                                     // cols % 8 == 0: a group of 4 is inside or outside as a whole
+            at[rg][g] = key.offset + (in_row[rg] ? row : last_row) * key.cols + (in_col[g] ? c : key.cols - 4);
+        }
+    }
+    auto load_base = [&](auto dt_tag) {
+        constexpr int BDT = decltype(dt_tag)::value;
+        typedef typename std::conditional<BDT == MECHA_F32, f32x4, u16x4>::type raw_t;
+        raw_t raw[2][4];
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) raw[rg][g] = *reinterpret_cast<const raw_t *>(base + at[rg][g] * (BDT == MECHA_F32 ? 4 : 2));
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int64_t c = bcol0 + wcol + 32 * cg + 8 * g + 4 * h;
-                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (base != nullptr && row < key.rows && c < key.cols) load4(p.base_dt, true, base, key.offset + row * key.cols + c, 4, v);
+                float v[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    float x;
+                    if constexpr (BDT == MECHA_F32) x = raw[rg][g][q4];
+                    else if constexpr (BDT == MECHA_BF16) x = bf16_bits_to_f32(raw[rg][g][q4]);
+                    else x = f16_bits_to_f32(raw[rg][g][q4]);
+                    v[q4] = (in_row[rg] && in_col[g]) ? x : 0.0f;
+                }
                 poison_in = __builtin_elementwise_fma(f32x2{v[0], v[1]}, zero2, poison_in);
                 poison_in = __builtin_elementwise_fma(f32x2{v[2], v[3]}, zero2, poison_in);
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) total[rg][cg][g * 4 + q4] = v[q4];
+                for (int q4 = 0; q4 < 4; q4++) total[rg][g * 4 + q4] = v[q4];
             }
-        }
-    }
+    };
+    if (base == nullptr) {
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) total[rg][i] = 0.0f;
+    } else if (p.base_dt == MECHA_BF16) load_base(std::integral_constant<int, MECHA_BF16>{});
+    else if (p.base_dt == MECHA_F16) load_base(std::integral_constant<int, MECHA_F16>{});
+    else load_base(std::integral_constant<int, MECHA_F32>{});
 
     u16x8v mag = {0, 0, 0, 0, 0, 0, 0, 0};                                                  // running max of |factor| bit patterns (edge tiles)
     const u16x8v abs_mask = {0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff};
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
     for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-        for (int cg = 0; cg < 2; cg++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[rg][cg][i] = 0.0f;
+        for (int i = 0; i < 16; i++) acc[rg][i] = 0.0f;
 
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     int done = 0;                                                         // chunks consumed so far
@@ -304,8 +335,8 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     auto round = [&](int slot) {
         const Chunk now = pending[slot];
         const int later = issued - done - 1;                              // stages issued after this one: 0 .. RING - 2
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -315,72 +346,56 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
             if (pending[refill].ok) { issue(pending[refill], refill); issued++; }
         }
         const unsigned char *stage = ring + slot * STAGE_BYTES;
-        u16x8 a[2][2], b[2][2];                                           // [k-step][column group], [k-step][row group]
+        u16x8 a[2], b[2][2];                                              // [k-step], [k-step][row group]
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-#pragma unroll
-            for (int cg = 0; cg < 2; cg++) {
-                const unsigned char *at = stage + a_lane + a_win[cg] + 16 * s * 256;
+            {
+                const unsigned char *at = stage + a_lane + a_win + 16 * s * 256;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at + 4 * 256));
-                a[s][cg] = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                a[s] = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
             for (int rg = 0; rg < 2; rg++) b[s][rg] = *reinterpret_cast<const u16x8 *>(stage + b_lane + (2 * s * 128 + 32 * rg) * 16);
         }
-        if (now.k0 == 0) {                                                // a network's first k-step starts from C = 0 (an inline constant: no register clears)
+        const mecha_lora_net net = nets[now.n];
+        // Consecutive networks with the same (scale, weight) share ONE accumulator chain and one fold (NET_* bits, set when
+        // the key is entered): sum_i fma(delta_i * s, w, .) and fma((sum_i delta_i) * s, w, .) differ by fp32 rounding of the
+        // partial sums only, inside the parity bar of this method (BLAS-ordered sgemm in the reference: <= 1 ulp of the output
+        // dtype).  A fold per rank-32 network cost as many instructions as its four MFMAs.
+        if (now.k0 == 0 && (net.reserved & NET_STARTS_GROUP)) {           // the chain starts from C = 0 (an inline constant: no register clears)
             const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int rg = 0; rg < 2; rg++) {
-                acc[rg][0] = mfma16<LDT>(a[0][0], b[0][rg], zero);
-                acc[rg][1] = mfma16<LDT>(a[0][1], b[0][rg], zero);
-            }
+            for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[0], b[0][rg], zero);
         } else {
 #pragma unroll
-            for (int rg = 0; rg < 2; rg++) {
-                acc[rg][0] = mfma16<LDT>(a[0][0], b[0][rg], acc[rg][0]);
-                acc[rg][1] = mfma16<LDT>(a[0][1], b[0][rg], acc[rg][1]);
-            }
+            for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[0], b[0][rg], acc[rg]);
         }
 #pragma unroll
-        for (int rg = 0; rg < 2; rg++) {
-            acc[rg][0] = mfma16<LDT>(a[1][0], b[1][rg], acc[rg][0]);
-            acc[rg][1] = mfma16<LDT>(a[1][1], b[1][rg], acc[rg][1]);
-        }
-        if (check_down) {                                                 // this thread's 32 bytes of the down slab
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + t * 32) & abs_mask);
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + t * 32 + 16) & abs_mask);
-        }
-        if (check_up) {
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + t * 32) & abs_mask);
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + t * 32 + 16) & abs_mask);
-        }
-        const mecha_lora_net net = nets[now.n];
-        if (now.k0 + KC >= net.rank) {                                    // the network is complete: delta * scale, then addcmul
+        for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[1], b[1][rg], acc[rg]);
+        if (check_down)                                                   // this thread's 16 bytes of the down slab
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + t * 16) & abs_mask);
+        if (check_up)
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + t * 16) & abs_mask);
+        if (now.k0 + KC >= net.rank && (net.reserved & NET_ENDS_GROUP)) { // the group is complete: delta * scale, then addcmul
             const float scale = net.scale, weight = net.weight;
             // fma(round(acc * scale), weight, total) (lycoris.py:263 then linear.py:76).  With a power-of-two scale (alpha / rank
             // usually is one) acc * scale and scale * weight are exact, so one fma gives the same bits; two per instruction
             // (v_pk_fma_f32).  Only results below the normal range could differ, where acc * scale would round and this does not.
-            const uint32_t sb = __float_as_uint(scale), swb = __float_as_uint(scale * weight);
-            const bool one_step = ((sb & 0x007fffffu) == 0u) && (((sb >> 23) & 0xffu) - 1u < 254u) && (((swb >> 23) & 0xffu) - 1u < 254u);
-            if (one_step) {
+            if (net.reserved & NET_ONE_STEP) {
                 const f32x2 sw = {scale * weight, scale * weight};
 #pragma unroll
                 for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-                    for (int cg = 0; cg < 2; cg++)
-#pragma unroll
-                        for (int i = 0; i < 16; i += 2) {
-                            const f32x2 f = __builtin_elementwise_fma(f32x2{acc[rg][cg][i], acc[rg][cg][i + 1]}, sw, f32x2{total[rg][cg][i], total[rg][cg][i + 1]});
-                            total[rg][cg][i] = f.x; total[rg][cg][i + 1] = f.y;
-                        }
+                    for (int i = 0; i < 16; i += 2) {
+                        const f32x2 f = __builtin_elementwise_fma(f32x2{acc[rg][i], acc[rg][i + 1]}, sw, f32x2{total[rg][i], total[rg][i + 1]});
+                        total[rg][i] = f.x; total[rg][i + 1] = f.y;
+                    }
             } else {
 #pragma unroll
                 for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-                    for (int cg = 0; cg < 2; cg++)
-#pragma unroll
-                        for (int i = 0; i < 16; i++) total[rg][cg][i] = __builtin_fmaf(acc[rg][cg][i] * scale, weight, total[rg][cg][i]);
+                    for (int i = 0; i < 16; i++) total[rg][i] = __builtin_fmaf(acc[rg][i] * scale, weight, total[rg][i]);
             }
         }
         done++;
@@ -397,25 +412,33 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     }
 
     f32x2 poison_out = {0.0f, 0.0f};
+    char *outp = static_cast<char *>(p.out);
+    auto store_out = [&](auto dt_tag) {
+        constexpr int ODT = decltype(dt_tag)::value;
 #pragma unroll
-    for (int rg = 0; rg < 2; rg++) {
-        const int64_t row = row0 + 32 * rg;
-#pragma unroll
-        for (int cg = 0; cg < 2; cg++) {
+        for (int rg = 0; rg < 2; rg++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int64_t c = bcol0 + wcol + 32 * cg + 8 * g + 4 * h;
-                if (row < key.rows && c < key.cols) {
+                if (in_row[rg] && in_col[g]) {
                     float v[4];
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) v[q4] = total[rg][cg][g * 4 + q4];
+                    for (int q4 = 0; q4 < 4; q4++) v[q4] = total[rg][g * 4 + q4];
                     poison_out = __builtin_elementwise_fma(f32x2{v[0], v[1]}, zero2, poison_out);
                     poison_out = __builtin_elementwise_fma(f32x2{v[2], v[3]}, zero2, poison_out);
-                    store4(p.out_dt, true, p.out, key.offset + row * key.cols + c, 4, v);
+                    if constexpr (ODT == MECHA_F32) {
+                        *reinterpret_cast<f32x4 *>(outp + at[rg][g] * 4) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        u16x4 w;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) w[q4] = (uint16_t)(ODT == MECHA_BF16 ? f32_to_bf16_bits(v[q4]) : f32_to_f16_bits(v[q4]));
+                        *reinterpret_cast<u16x4 *>(outp + at[rg][g] * 2) = w;
+                    }
                 }
             }
-        }
-    }
+    };
+    if (p.out_dt == MECHA_BF16) store_out(std::integral_constant<int, MECHA_BF16>{});
+    else if (p.out_dt == MECHA_F16) store_out(std::integral_constant<int, MECHA_F16>{});
+    else store_out(std::integral_constant<int, MECHA_F32>{});
     bool bad_in = (poison_in.x != poison_in.x) || (poison_in.y != poison_in.y);
     const bool bad_out = (poison_out.x != poison_out.x) || (poison_out.y != poison_out.y);
     const uint16_t inf_bits = LDT == MECHA_F16 ? 0x7c00 : 0x7f80;
@@ -425,46 +448,10 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
         atomicOr(p.flags + key_index, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
 }
 
-// FAST: the kernel of the common case (its tiles only); !FAST: the general path (the other tiles only).  Two kernels rather
-// than one branch: together they do not fit the 256 registers of two waves per SIMD.
-template <int LDT, bool BATCHED, bool FAST>
-__global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FAST ? RING * STAGE_BYTES : 2 * SLAB_HALFS * 2];
-    uint16_t (&lds)[2][SLAB_HALFS] = *reinterpret_cast<uint16_t (*)[2][SLAB_HALFS]>(lds_raw);
-    // ---- which key, which tile
-    int64_t tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= tiles_per_xcd || tile >= n_tiles) return;      // whole block
-    mecha_lora_key key;
-    const mecha_lora_net *nets;
-    int key_index = 0;
-    if constexpr (BATCHED) {
-        int lo = 0, hi = p.n_keys - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (p.keys[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
-        }
-        key_index = lo;
-        key = p.keys[lo];
-        nets = p.nets + key.net_begin;
-        tile -= key.tile_start;
-    } else {
-        key = p.key0;
-        nets = p.net0;
-    }
-    const int64_t tiles_x = (key.cols + LORA_TILE - 1) / LORA_TILE;
-    const int64_t tile_y = tile / tiles_x, tile_x = tile % tiles_x;
-    {
-        bool fast = ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 3) == 0) && key.rows < ((int64_t)1 << 31);
-        for (int i = 0; i < key.net_count && fast; i++) {
-            const mecha_lora_net net = nets[i];
-            fast = ((net.rank & 31) == 0) && (((reinterpret_cast<uintptr_t>(net.up) | reinterpret_cast<uintptr_t>(net.down)) & 15u) == 0) &&
-                   (key.rows * (int64_t)net.rank < ((int64_t)1 << 30));
-        }
-        if (fast != FAST) return;                                         // block-uniform: the other kernel's tile
-    }
-    if constexpr (FAST) {
-        lora_tile_fast<LDT>(p, key, nets, key_index, tile_x, tile_y, lds_raw);
-    } else {
+// the general path for one tile: any rank, any alignment (scalar edge accesses, every load guarded)
+template <int LDT>
+__device__ __forceinline__ void lora_tile_general(const LoraParams &p, const mecha_lora_key &key, const mecha_lora_net *nets, int key_index,
+                                                  int64_t tile_x, int64_t tile_y, uint16_t (&lds)[2][SLAB_HALFS]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     // transposed product: MFMA rows <-> output columns, MFMA columns <-> output rows
@@ -618,6 +605,86 @@ __global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int6
     }
     if ((bad_in | bad_out) && p.flags != nullptr)
         atomicOr(p.flags + key_index, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+}
+
+// FAST: the kernel of the common case (its keys only); !FAST: the general path (the other keys only).  Two kernels rather
+// than one branch: the fast path runs 8 waves per block, the general one 4, and together they do not fit the registers.
+// Both are persistent: the grid is one resident set of blocks, dealt round-robin over the 8 XCDs (each with its own L2);
+// XCD x works through the contiguous tile range [x, x + 1) * tiles_per_xcd, its blocks side by side (block j takes every
+// nb-th tile), so a key's factors are fetched into one L2 and stay there while the key lasts (a contiguous run per block
+// was measured first: 32 keys per XCD in flight, 83 MB of factors against 4 MB of L2, the factor reads went to HBM:
+// 14.9 ms for the SDXL x16 batch).  A block walks the key table forward with a parallel search.  On a key change the key's network table goes to LDS with one parallel load
+// (every later access is an LDS read: a global load inside the k-loop would have to wait out the LDS-DMA ring, vmcnt is
+// in order) and the same threads evaluate the fast / general test.
+constexpr int LORA_FAST_BLOCK = 512;            // the fast kernel: 8 waves, wave tile 32 columns x 64 rows
+template <int LDT, bool BATCHED, bool FAST>
+__global__ __launch_bounds__(FAST ? LORA_FAST_BLOCK : MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FAST ? RING * STAGE_BYTES : 2 * SLAB_HALFS * 2];
+    __shared__ __attribute__((aligned(16))) mecha_lora_net s_nets[LORA_MAX_NETS];
+    uint16_t (&lds)[2][SLAB_HALFS] = *reinterpret_cast<uint16_t (*)[2][SLAB_HALFS]>(lds_raw);
+    // ---- this block's tiles: x0 + j, x0 + j + nb, ... of its XCD's range (the XCD's resident blocks work on neighbouring
+    // tiles at any moment: one key's factors in the L2, not one key per block)
+    const int64_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = gridDim.x >> 3;
+    const int64_t x0 = xcd * tiles_per_xcd, x1 = (x0 + tiles_per_xcd < n_tiles) ? x0 + tiles_per_xcd : n_tiles;
+    if (x0 + j >= x1) return;                                            // whole block
+    mecha_lora_key key;
+    int key_index = 0;
+    int64_t key_end = 0;                                                  // first tile after the key
+    bool fast = false;
+    // last key at or after `from` whose tile_start is <= t.  One parallel load of a window of tile_starts (sorted) and a
+    // block-wide count instead of a chain of dependent loads; the stride of the walk skips at most nb keys.
+    auto seek_key = [&](int from, int64_t t) {
+        while (true) {
+            const int mine = from + (int)threadIdx.x;
+            const int pred = mine < p.n_keys && p.keys[mine].tile_start <= t;
+            const int n = __syncthreads_count(pred);
+            if (n < (int)blockDim.x || from + n >= p.n_keys) return from + n - 1;
+            from += n - 1;
+        }
+    };
+    auto enter_key = [&](int ki) {                                        // block-uniform; called after a barrier
+        key_index = ki;
+        if constexpr (BATCHED) key = p.keys[ki]; else key = p.key0;
+        const int64_t tiles_x = (key.cols + LORA_TILE - 1) / LORA_TILE, tiles_y = (key.rows + LORA_TILE - 1) / LORA_TILE;
+        key_end = key.tile_start + tiles_x * tiles_y;
+        int ok = ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 3) == 0) && key.rows < ((int64_t)1 << 31);
+        if ((int)threadIdx.x < key.net_count) {
+            mecha_lora_net net;
+            if constexpr (BATCHED) net = p.nets[key.net_begin + threadIdx.x]; else net = p.net0[threadIdx.x];
+            // group bits for the fast path: neighbours with the same (scale, weight) share an accumulator chain
+            const int i = threadIdx.x;
+            mecha_lora_net prev = net, next = net;
+            if constexpr (BATCHED) {
+                if (i > 0) prev = p.nets[key.net_begin + i - 1];
+                if (i + 1 < key.net_count) next = p.nets[key.net_begin + i + 1];
+            } else {
+                if (i > 0) prev = p.net0[i - 1];
+                if (i + 1 < key.net_count) next = p.net0[i + 1];
+            }
+            auto same = [](const mecha_lora_net &x, const mecha_lora_net &y) {
+                return __float_as_uint(x.scale) == __float_as_uint(y.scale) && __float_as_uint(x.weight) == __float_as_uint(y.weight);
+            };
+            const uint32_t sb = __float_as_uint(net.scale), swb = __float_as_uint(net.scale * net.weight);
+            const bool one_step = ((sb & 0x007fffffu) == 0u) && (((sb >> 23) & 0xffu) - 1u < 254u) && (((swb >> 23) & 0xffu) - 1u < 254u);
+            net.reserved = ((i == 0 || !same(prev, net)) ? NET_STARTS_GROUP : 0) | ((i + 1 == key.net_count || !same(next, net)) ? NET_ENDS_GROUP : 0) |
+                           (one_step ? NET_ONE_STEP : 0);
+            s_nets[threadIdx.x] = net;
+            ok = ok && ((net.rank & 31) == 0) && (((reinterpret_cast<uintptr_t>(net.up) | reinterpret_cast<uintptr_t>(net.down)) & 15u) == 0) &&
+                 (key.rows * (int64_t)net.rank < ((int64_t)1 << 30));
+        }
+        fast = __syncthreads_and(ok) != 0;
+    };
+    for (int64_t t = x0 + j; t < x1; t += nb) {
+        __syncthreads();                                                  // the previous tile's readers of the LDS stages and of s_nets are done
+        if (t >= key_end) {
+            if constexpr (BATCHED) enter_key(seek_key(key_index, t)); else enter_key(0);
+        }
+        if (fast != FAST) continue;                                       // the other kernel's key
+        const int64_t local = t - key.tile_start;
+        const int64_t tiles_x = (key.cols + LORA_TILE - 1) / LORA_TILE;
+        const int64_t tile_y = local / tiles_x, tile_x = local % tiles_x;
+        if constexpr (FAST) lora_tile_fast<LDT>(p, key, s_nets, key_index, tile_x, tile_y, lds_raw);
+        else lora_tile_general<LDT>(p, key, s_nets, key_index, tile_x, tile_y, lds);
     }
 }
 
@@ -630,12 +697,30 @@ bool key_is_fast(const mecha_lora_key &key) {
     return ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 3) == 0) && key.rows < ((int64_t)1 << 31);
 }
 
+// blocks of `kernel` that fit one CU at once (asked once per kernel and device)
+template <typename K>
+int resident_blocks_per_cu(K kernel, int block) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    return n;
+}
+
 template <int LDT, bool BATCHED>
 int launch_lora(const LoraParams &p, int64_t tiles, bool any_fast, bool any_general, hipStream_t s) {
-    MECHA_REQUIRE(tiles + 8 <= 0x7fffffff, "grid too large");
+    MECHA_REQUIRE(tiles + 8 <= 0x7fffffff, "too many tiles");
     const int64_t per_xcd = (tiles + 7) / 8;
-    if (any_fast) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, true>), dim3((unsigned)(per_xcd * 8)), dim3(MECHA_BLOCK), 0, s, p, tiles, per_xcd);
-    if (any_general) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, false>), dim3((unsigned)(per_xcd * 8)), dim3(MECHA_BLOCK), 0, s, p, tiles, per_xcd);
+    int dev = 0, cus = 256;
+    MECHA_CHECK_HIP(hipGetDevice(&dev));
+    MECHA_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    static const int occ_fast = resident_blocks_per_cu(lora_kernel<LDT, BATCHED, true>, LORA_FAST_BLOCK);
+    static const int occ_general = resident_blocks_per_cu(lora_kernel<LDT, BATCHED, false>, MECHA_BLOCK);
+    auto grid_for = [&](int occ) {
+        int64_t per_xcd_blocks = ((int64_t)cus * occ + 7) / 8;
+        if (per_xcd_blocks > per_xcd) per_xcd_blocks = per_xcd;
+        return dim3((unsigned)(per_xcd_blocks * 8));
+    };
+    if (any_fast) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, true>), grid_for(occ_fast), dim3(LORA_FAST_BLOCK), 0, s, p, tiles, per_xcd);
+    if (any_general) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, false>), grid_for(occ_general), dim3(MECHA_BLOCK), 0, s, p, tiles, per_xcd);
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;
 }
