@@ -466,6 +466,12 @@ def _fusable_dtypes(plan: FusedPlan, readers, items) -> bool:
     return len(dts) == 1 and next(iter(dts)) in _DT_CODE
 
 
+class NullSink(dict):
+    """``merge(output=NullSink())``: every key is merged and copied back to pinned host memory, then dropped.  For timing
+    the files -> staging -> H2D -> kernels -> D2H pipeline without the cost of an output file (tools/bench_e2e.py --sink none)."""
+    discard = True
+
+
 # ------------------------------------------------------------------ fused (batched) path
 def _run_fused(plan, backend, readers, items, header, sink, to_file, output_device, output_dtype, total_buffer_size,
                check_finite_output, skipped):
@@ -609,6 +615,8 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
                 put_keys.append(key)
                 put_metas.append(meta)
                 put_ptrs.append(out_base + off * out_esz)
+            elif getattr(sink, "discard", False):
+                continue                                                     # NullSink: results stay in the staging buffer (link timing)
             else:
                 t = bs["h_out"][off:off + n].clone().view(meta.shape)
                 sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t

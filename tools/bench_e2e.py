@@ -32,7 +32,11 @@ WORKLOADS = {
     "sd1_wsum": ("sd1-ldm", None, 2, "wsum"),
     # BASELINE config 5: one base (kohya key naming) + 16 kohya LoRA files, rank 32, fp16, alpha 16, weight 1.0
     "sdxl_lora": ("sdxl-kohya", None, 1, "lora"),
+    # BASELINE config 3, one GPU's share: stripe 0 of the 8 key stripes (LPT) of the FLUX-dev diffuser, 8 checkpoints
+    "flux_navg": ("flux-flux", ("diffuser",), 8, "navg"),
+    "flux_ties": ("flux-flux", ("diffuser",), 8, "ties"),
 }
+STRIPES = {"flux_navg": 8, "flux_ties": 8}
 N_LORAS, LORA_RANK = 16, 32
 
 
@@ -86,9 +90,16 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/mecha_e2e")
     ap.add_argument("--buffer-gib", type=float, default=16.0, help="total_buffer_size of merge() (pinned staging budget)")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--sink", default="file", choices=["file", "none"],
+                    help="file: one .safetensors on --dir; none: results come back to pinned host memory and are dropped "
+                         "(the host-link pipeline alone: files -> staging -> H2D -> kernels -> D2H)")
     args = ap.parse_args()
     manifest_id, comps, n_models, recipe_kind = WORKLOADS[args.workload]
     manifest = [(k, s, d) for k, s, d in load_manifest(manifest_id, comps) if not d.startswith("int")]
+    if args.workload in STRIPES:
+        from sd_mecha_amd.arena import shard_keys_lpt
+        mine = {k for k, _ in shard_keys_lpt([(k, numel(s)) for k, s, _ in manifest], STRIPES[args.workload])[0]}
+        manifest = [(k, s, d) for k, s, d in manifest if k in mine]
     device = torch.device("cuda", 0)
     work = pathlib.Path(args.dir)
     work.mkdir(parents=True, exist_ok=True)
@@ -128,13 +139,16 @@ def main():
                 out.unlink()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            amd.merge(recipe, output=str(out), output_dtype=torch.bfloat16, total_buffer_size=int(args.buffer_gib * 2 ** 30))
-            times.append(time.perf_counter() - t0)
             from sd_mecha_amd import merging
+            amd.merge(recipe, output=str(out) if args.sink == "file" else merging.NullSink(), output_dtype=torch.bfloat16,
+                      total_buffer_size=int(args.buffer_gib * 2 ** 30))
+            times.append(time.perf_counter() - t0)
             print("phases (host seconds):", {k: round(v, 3) for k, v in merging.last_stats.items()}, file=sys.stderr, flush=True)
         best = min(times)
         line = {
-            "metric": "merged state-dict GB/s, end to end (files on tmpfs -> file on tmpfs)", "workload": args.workload,
+            "metric": "merged state-dict GB/s, end to end (files on tmpfs -> file on tmpfs)" if args.sink == "file" else
+                      "merged state-dict GB/s, host-link pipeline (files on tmpfs -> pinned staging -> H2D -> kernels -> D2H -> pinned, no output file)",
+            "workload": args.workload, "sink": args.sink,
             "value": round(moved / best / 1e9, 2), "unit": "GB/s", "seconds": [round(t, 3) for t in times],
             "bytes_moved": moved, "elements": elems, "keys": len(manifest), "n_models": n_models,
             "total_buffer_size_gib": args.buffer_gib, "host_link_GBs": link_rate(device),
@@ -142,6 +156,7 @@ def main():
         }
         lr = line["host_link_GBs"]
         line["link_bound_seconds"] = round(max(elems * 2 * n_models / (lr["h2d"] * 1e9), elems * 2 / (lr["d2h"] * 1e9)), 3)
+        line["host_link_frac"] = round(line["link_bound_seconds"] / best, 4)      # 1.0 = the slower direction of the link busy all the time
         print(json.dumps(line), flush=True)
     finally:
         shutil.rmtree(work, ignore_errors=True)
