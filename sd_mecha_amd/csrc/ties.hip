@@ -633,6 +633,7 @@ struct MergeExtra {
     float rescale_div;      // DARE: divide by (1 - probability), or 1
     int vote_sgn;
     int has_rescale;
+    int skip_full_tiles;    // 1: ties_merge_full_kernel runs too and owns the full tiles of the keys it accepts
 };
 
 __device__ __forceinline__ float sign_f(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }   // torch.sign: sign(+-0) = 0
@@ -705,6 +706,8 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             }
         }
         const mecha_segment seg = cur.seg;
+        // the same test as in ties_merge_full_kernel: that kernel merges this tile
+        if (x.skip_full_tiles && in_regs && fast_div && (t - cur.first + 1) * TIES_TILE <= seg.numel) continue;
 #pragma unroll 1
         for (int u = 0; u < 2; u++) {
             const int64_t local = (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
@@ -853,6 +856,215 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
                 if (slot < p.amb_capacity) { p.hit_elem[slot] = e; p.hit_seg[slot] = (uint32_t)cur.s; }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ merge, full tiles
+// The common case as straight-line code: add_difference(base, ties_sum(models - base)) with 1..8 models in 16-bit storage,
+// sign election by count, every threshold of the key >= 2^-90 (no kept delta is a zero, the fma division is exact) and a
+// tile that lies whole inside its key.  Everything else (ragged last tiles, tiny keys, zero thresholds, DARE, vote_sgn, fp32
+// storage, 9+ models) stays with ties_merge_kernel above, which skips the tiles merged here (MergeExtra::skip_full_tiles).
+// Same values as that kernel, bit for bit, with about half the vector instructions per element (it was VALU-bound: 79
+// instructions per element against 5.2 TB/s worth of loads and stores):
+//   * s_m = sign of the filtered delta as an integer (v_med3_i32 of the bit pattern; no -0 to normalise when thr > 0);
+//     vote = s_1 + .. + s_N in one v_add3; elected sign = med3(vote, -1, 1);
+//   * the agreeing deltas are selected by s_m == elected and summed signed, in index order from +0: the same roundings as the
+//     sum of magnitudes times the sign (addition is symmetric under negation);
+//   * the agree count needs no pass of its own: agreeing - disagreeing = |vote| and agreeing + disagreeing = kept, so
+//     count = (vote * elected + kept) / 2, kept counted by the filter's own compare (elected = 0: every selected value is a
+//     zero, the quotient is +0 or 0 * inf = NaN -> 0, like the reference's 0 / count);
+//   * subtraction, sums and the finishing fmas on two values per instruction (v_pk_add_f32 / v_pk_fma_f32).
+template <int DT>
+__device__ __forceinline__ void unpack_pairs(u32x4 r, f32x2 (&v)[4]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if constexpr (DT == MECHA_BF16) v[q] = f32x2{__uint_as_float(w[q] << 16), __uint_as_float(w[q] & 0xffff0000u)};
+        else v[q] = f32x2{f16_bits_to_f32(w[q] & 0xffffu), f16_bits_to_f32(w[q] >> 16)};
+    }
+}
+// clamp to [-1, 1]: the sign of an integer, or of a float's bit pattern (no -0 here).  As inline assembly: written as min(max())
+// the compiler recognises a sign function and emits two compares and two selects instead of the one v_med3_i32.
+__device__ __forceinline__ int sign_i32(int v) {
+    int r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+template <int N, int DT, int ODT>
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
+    const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
+    const long long t0 = (long long)blockIdx.x * chunk;
+    const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
+    __shared__ float recip[16];                    // correctly rounded 1 / count, [0] = +inf
+    if (threadIdx.x < 16) recip[threadIdx.x] = 1.0f / (float)threadIdx.x;
+    __syncthreads();
+    TileCursor cur;
+    float thr[N], amb_hi[N];
+    bool key_ok = false, any_amb = false;
+#pragma unroll
+    for (int d = 0; d < N; d++) { thr[d] = 0.0f; amb_hi[d] = -1.0f; }
+    const uint16_t *base = static_cast<const uint16_t *>(p.base);
+    const f32x2 zero2 = {0.0f, 0.0f};
+    const f32x2 alpha2 = {x.alpha, x.alpha};
+    for (long long t = t0; t < t1; t++) {
+        const int prev = cur.s;
+        cursor_seek(p, t, cur);
+        if (cur.s != prev) {
+            const SelectState *st = p.state + (int64_t)cur.s * N;
+            key_ok = true; any_amb = false;
+#pragma unroll
+            for (int d = 0; d < N; d++) {
+                thr[d] = prov_threshold(st[d]);
+                amb_hi[d] = (st[d].mode == MODE_AMBIG) ? __uint_as_float(st[d].amb_hi) : -1.0f;
+                key_ok = key_ok && (thr[d] >= 0x1p-90f);
+                any_amb = any_amb || (amb_hi[d] >= 0.0f);
+            }
+        }
+        if (!key_ok || (t - cur.first + 1) * TIES_TILE > cur.seg.numel) continue;     // ties_merge_kernel's tile
+        bool bad = false, bad_o = false, hit_any = false;
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+            const int64_t e = cur.seg.offset + (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
+            // every load of this position is issued before the first one is consumed
+            u32x4 rv[N];
+            const u32x4 rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + e));
+#pragma unroll
+            for (int m = 0; m < N; m++) rv[m] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(p.in[m]) + e));
+            f32x2 b2[4];
+            unpack_pairs<DT>(rb, b2);
+            f32x2 poison = zero2;                  // fma(x, 0, poison): 0 while every input is finite, NaN after inf / NaN
+#pragma unroll
+            for (int q = 0; q < 4; q++) poison = __builtin_elementwise_fma(b2[q], zero2, poison);
+            int kept[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) kept[j] = 0;
+            bool hit = false;
+            f32x2 acc[4];
+            int cnt[8];
+            if constexpr (N <= 4) {
+                // one sweep: the filtered deltas and their signs stay in registers
+                float f[N][8];
+                int sgn[N][8];
+#pragma unroll
+                for (int m = 0; m < N; m++) {
+                    f32x2 v2[4];
+                    unpack_pairs<DT>(rv[m], v2);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) poison = __builtin_elementwise_fma(v2[q], zero2, poison);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v2[q] = v2[q] - b2[q];                     // subtract (linear.py:101)
+                    if (any_amb && amb_hi[m] >= 0.0f) {                                    // wave-uniform and rare
+#pragma unroll
+                        for (int j = 0; j < 8; j++) hit |= (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float d = v2[j >> 1][j & 1];
+                        const bool keep = __builtin_fabsf(d) >= thr[m];                    // filter_top_k (ties.py:128-132)
+                        kept[j] += keep ? 1 : 0;
+                        f[m][j] = keep ? d : 0.0f;
+                        sgn[m][j] = sign_i32(__float_as_int(f[m][j]));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int j = 2 * q + h;
+                        int vote = sgn[0][j];
+#pragma unroll
+                        for (int m = 1; m < N; m++) vote += sgn[m][j];
+                        const int fs = sign_i32(vote);
+                        cnt[j] = (vote * fs + kept[j]) >> 1;
+#pragma unroll
+                        for (int m = 0; m < N; m++) f[m][j] = (sgn[m][j] == fs) ? f[m][j] : 0.0f;
+                    }
+                    acc[q] = zero2;
+#pragma unroll
+                    for (int m = 0; m < N; m++) acc[q] = acc[q] + f32x2{f[m][2 * q], f[m][2 * q + 1]};   // index order, from +0 (ties.py:123)
+                }
+            } else {
+                // 5..8 models: two sweeps over the raw words (4 registers per model instead of 16 for delta and sign)
+                int vote[8], fs[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) vote[j] = 0;
+#pragma unroll
+                for (int m = 0; m < N; m++) {
+                    f32x2 v2[4];
+                    unpack_pairs<DT>(rv[m], v2);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) poison = __builtin_elementwise_fma(v2[q], zero2, poison);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v2[q] = v2[q] - b2[q];
+                    if (any_amb && amb_hi[m] >= 0.0f) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) hit |= (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float d = v2[j >> 1][j & 1];
+                        const bool keep = __builtin_fabsf(d) >= thr[m];
+                        kept[j] += keep ? 1 : 0;
+                        vote[j] += sign_i32(__float_as_int(keep ? d : 0.0f));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    fs[j] = sign_i32(vote[j]);
+                    cnt[j] = (vote[j] * fs[j] + kept[j]) >> 1;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = zero2;
+#pragma unroll
+                for (int m = 0; m < N; m++) {
+                    f32x2 v2[4];
+                    unpack_pairs<DT>(rv[m], v2);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v2[q] = v2[q] - b2[q];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        f32x2 g;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const float d = v2[q][h];
+                            // kept and of the elected sign (elected 0: only a zero delta could match, and that one is not kept)
+                            const bool agree = (__builtin_fabsf(d) >= thr[m]) & (sign_i32(__float_as_int(d)) == fs[2 * q + h]);
+                            g[h] = agree ? d : 0.0f;
+                        }
+                        acc[q] = acc[q] + g;
+                    }
+                }
+            }
+            f32x2 r2[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // filtered_delta / param_counts (ties.py:124), correctly rounded: y = RN(1 / count), q0 = RN(a y),
+                // q = RN(q0 + (a - count q0) y)  (see ties_merge_kernel)
+                const f32x2 y = {recip[cnt[2 * q]], recip[cnt[2 * q + 1]]};
+                const f32x2 negc = {-(float)cnt[2 * q], -(float)cnt[2 * q + 1]};
+                const f32x2 q0 = acc[q] * y;
+                f32x2 qq = __builtin_elementwise_fma(__builtin_elementwise_fma(negc, q0, acc[q]), y, q0);
+                qq.x = __builtin_amdgcn_class(qq.x, 0x1f8) ? qq.x : 0.0f;              // nan_to_num(nan=0, posinf=0, neginf=0)
+                qq.y = __builtin_amdgcn_class(qq.y, 0x1f8) ? qq.y : 0.0f;
+                r2[q] = __builtin_elementwise_fma(qq, alpha2, b2[q]);                  // base.addcmul(ties, alpha)  (linear.py:76)
+            }
+            f32x2 out_poison = zero2;
+#pragma unroll
+            for (int q = 0; q < 4; q++) out_poison = __builtin_elementwise_fma(r2[q], zero2, out_poison);
+            const float r[8] = {r2[0].x, r2[0].y, r2[1].x, r2[1].y, r2[2].x, r2[2].y, r2[3].x, r2[3].y};
+            store8<ODT, true>(out, e, r);
+            bad |= (poison.x != poison.x) | (poison.y != poison.y);
+            bad_o |= (out_poison.x != out_poison.x) | (out_poison.y != out_poison.y);
+            if (hit) {
+                const unsigned long long slot = atomicAdd(&p.globals->n_hit, 1ull);
+                if (slot < p.amb_capacity) { p.hit_elem[slot] = e; p.hit_seg[slot] = (uint32_t)cur.s; }
+            }
+            hit_any |= hit;
+        }
+        if ((bad | bad_o) && flags != nullptr)
+            atomicOr(flags + (p.tile_start == nullptr ? 0 : cur.s), (bad ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_o ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+        (void)hit_any;
     }
 }
 
@@ -1194,10 +1406,35 @@ void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float 
     MECHA_LAUNCH(MK_TIES_SCAN, (ties_scan_kernel<3>), dim3(scan_grid), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, thresholds_out);
 }
 
+template <int N, int DT>
+void launch_merge_full(const TiesParams &p, const MergeExtra &x, unsigned grid, void *out, uint32_t *flags, hipStream_t s) {
+    if (p.out_dt == MECHA_BF16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_BF16>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    else if (p.out_dt == MECHA_F16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F16>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F32>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+}
+
 template <bool DARE>
-void launch_merge(const TiesParams &p, const MergeExtra &x, unsigned grid, void *out, uint32_t *flags, hipStream_t s) {
+void launch_merge(const TiesParams &p, const MergeExtra &x_in, unsigned grid, void *out, uint32_t *flags, hipStream_t s) {
     const bool w32 = p.in_dt == MECHA_F32;
-#define MECHA_MERGE_LAUNCH(CAP_, W32_) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_kernel<CAP_, DARE, W32_>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags)
+    MergeExtra x = x_in;
+    // the common case goes to ties_merge_full_kernel; ties_merge_kernel then only sees what that kernel leaves (timed as
+    // "ties_fixup" so that the per-launch average of "ties_merge" stays that of the full-tile kernel)
+    const bool full = !DARE && p.base != nullptr && !w32 && p.vec_ok && !x.vote_sgn && !x.has_rescale && p.n_deltas <= 8 && out != nullptr &&
+                      mecha_aligned16(out);
+    if (full) {
+        x.skip_full_tiles = 1;
+#define MECHA_FULL_CASE(N_) case N_: if (p.in_dt == MECHA_BF16) launch_merge_full<N_, MECHA_BF16>(p, x, grid, out, flags, s); \
+                                      else launch_merge_full<N_, MECHA_F16>(p, x, grid, out, flags, s); break;
+        switch (p.n_deltas) {
+            MECHA_FULL_CASE(1) MECHA_FULL_CASE(2) MECHA_FULL_CASE(3) MECHA_FULL_CASE(4)
+            MECHA_FULL_CASE(5) MECHA_FULL_CASE(6) MECHA_FULL_CASE(7)
+            default: if (p.in_dt == MECHA_BF16) launch_merge_full<8, MECHA_BF16>(p, x, grid, out, flags, s);
+                     else launch_merge_full<8, MECHA_F16>(p, x, grid, out, flags, s);
+        }
+#undef MECHA_FULL_CASE
+    }
+    const int id = full ? MK_TIES_FIXUP : MK_TIES_MERGE;
+#define MECHA_MERGE_LAUNCH(CAP_, W32_) MECHA_LAUNCH(id, (ties_merge_kernel<CAP_, DARE, W32_>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags)
     if (p.n_deltas <= 2) { if (w32) MECHA_MERGE_LAUNCH(2, true); else MECHA_MERGE_LAUNCH(2, false); }
     else if (p.n_deltas <= 4) { if (w32) MECHA_MERGE_LAUNCH(4, true); else MECHA_MERGE_LAUNCH(4, false); }
     else { if (w32) MECHA_MERGE_LAUNCH(8, true); else MECHA_MERGE_LAUNCH(8, false); }

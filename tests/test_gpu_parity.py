@@ -209,7 +209,8 @@ def test_unaligned_views_take_the_scalar_path(amd, oracle):
     assert ulp_distance_half(host_bits(got), want).max() <= 1
 
 
-@pytest.mark.parametrize("n_models,k", [(1, 0.5), (3, 0.2), (7, 0.2), (3, 1.0), (3, 0.0), (9, 0.35)])
+# every model count has its own instance of the full-tile merge kernel (1..8 models; 9 stays with the general kernel)
+@pytest.mark.parametrize("n_models,k", [(1, 0.5), (3, 0.2), (7, 0.2), (3, 1.0), (3, 0.0), (9, 0.35), (2, 0.3), (4, 0.2), (5, 0.2), (6, 0.5), (8, 0.2)])
 def test_ties_vs_oracle(amd, oracle, n_models, k):
     rng = np.random.default_rng(1000 + n_models)
     for n in [1, 7, 4096, 4099, 300_000, (1 << 21) + 5]:
