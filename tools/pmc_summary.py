@@ -16,7 +16,7 @@ for f in root.rglob("*counter_collection.csv"):
             name = row["Kernel_Name"]
             if want not in name:
                 continue
-            short = name.split("(")[0][-60:]
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-70:]
             acc[short][row["Counter_Name"]] += float(row["Counter_Value"])
             key = (short, row["Dispatch_Id"])
             if key not in seen:
