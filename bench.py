@@ -197,9 +197,13 @@ def main():
             "ties_hist1": elems * 2 * job.n_models, "ties_hist2": elems * 2 * job.n_models, "ties_hist3": elems * 2 * job.n_models,
             "ties_count": elems * 2 * job.n_models, "ties_merge": elems * 2 * (job.n_models + 1),
         }
-        breakdown = {k: {"ms_total": round(ms, 3), "launches": n, "ms_avg": round(ms / n, 4)} for k, (ms, n) in kernels.items()}
+        breakdown = {k: {"ms_total": round(ms, 3), "launches": n, "ms_avg": round(ms / n, 4), "ms_per_step": round(ms / args.steps, 4)}
+                     for k, (ms, n) in kernels.items()}
+        # a kernel family may take several launches per step (the count pass runs once per group of 4 models): the roofline
+        # figure is the family's algorithmic bytes per step over its time per step
         dom = max((k for k in kernels if k in per_launch_bytes), key=lambda k: kernels[k][0])
-        dom_ms = kernels[dom][0] / kernels[dom][1]
+        dom_ms = kernels[dom][0] / args.steps
+        dom_launches_per_step = kernels[dom][1] / args.steps
         achieved = per_launch_bytes[dom] / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: they need rocprofv3, so they are collected in separate runs of this
         # same command and committed under profiles/ (how: the file's "_how"); None when this workload was not measured
@@ -217,7 +221,8 @@ def main():
             "hbm_frac_whole_step": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_launch_bytes[dom], "avg_launch_ms": round(dom_ms, 4)},
+                         "algorithmic_bytes_per_launch": per_launch_bytes[dom], "avg_launch_ms": round(dom_ms, 4),
+                         "launches_per_step": dom_launches_per_step},
             "kernels": breakdown,
         }
         if job.recipe == "ties":

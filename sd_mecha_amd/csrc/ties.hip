@@ -1380,7 +1380,10 @@ void launch_hist(const TiesParams &p, unsigned grid, hipStream_t s) {
 }
 
 void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
-    constexpr int COUNT_GROUP = 7;                 // 7 histograms + counters + dump words stay inside 64 KiB of LDS
+    // 4 histograms per block (33 KiB of LDS, 4 blocks per CU).  7 fit in 64 KiB and read the base once instead of twice for a
+    // FLUX x8 job, but at 2 blocks per CU the pass is latency-bound: measured on one FLUX stripe 6.18 ms in one launch of 7
+    // against 2 x 2.48 ms in groups of 4 + 3 (groups of 3: 5.56 ms, of 2: 5.77 ms).
+    constexpr int COUNT_GROUP = 4;
     for (int d0 = 0; d0 < p.n_deltas; d0 += COUNT_GROUP) {
         const int nd = (p.n_deltas - d0 < COUNT_GROUP) ? p.n_deltas - d0 : COUNT_GROUP;
         // LDS: nd histograms, 2 * CAP counters, 64 dump words
