@@ -139,12 +139,13 @@ __device__ __forceinline__ TileRegs tile_load(const Operand &op, int64_t m0, int
                 for (int j = 0; j < 4; j++) t.v[h][j] = (k < k_end && m + j < M) ? op.p[k * op.ks + m + j] : 0.0f;
             }
         }
-    } else if (op.ks == 1) {           // k-contiguous: thread = (m = tid % 64, 4 consecutive k at 4 * (tid / 64) [+16])
-        const int64_t m = m0 + (tid & 63);
+    } else if (op.ks == 1) {           // k-contiguous: thread = (m = tid / 8 [+32], 4 consecutive k at 4 * (tid % 8)): 8 lanes
+        // cover the 128 contiguous bytes of one row, a wave instruction touches 8 rows (one lane per row: 64 rows, 16 B of each)
+        const int64_t k = k0 + 4 * (tid & 7);
         const bool vec = ((op.ms & 3) == 0) && ((k0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(op.p) & 15u) == 0);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int64_t k = k0 + 4 * (tid >> 6) + 16 * h;
+            const int64_t m = m0 + (tid >> 3) + 32 * h;
             if (m < M && k + 4 <= k_end && vec) t.v[h] = *reinterpret_cast<const f32x4 *>(op.p + m * op.ms + k);
             else {
 #pragma unroll
@@ -170,7 +171,7 @@ __device__ __forceinline__ void tile_store(const Operand &op, const TileRegs &t,
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) lds[(4 * (tid >> 6) + 16 * h + j) * GP + (tid & 63)] = t.v[h][j];
+            for (int j = 0; j < 4; j++) lds[(4 * (tid & 7) + j) * GP + (tid >> 3) + 32 * h] = t.v[h][j];
     } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -219,6 +220,126 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, float *
         const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kk, col = n0 + i;
         if (row < M && col < N) gemm_store(ee, c, N, row, col, acc[r], bad);
     }
+    if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
+}
+
+// The same product for outputs of at least 256 x 256: block tile 128 x 128, wave tile 64 x 64 = 2 x 2 accumulators.  Every LDS
+// read feeds two MFMAs and a wave has four independent accumulator chains, so one or two blocks per CU keep the matrix
+// pipes fed (the 64 x 64 kernel: one dependent chain per wave, 400 small blocks for a 1280 x 1280 product).  16-deep
+// k-chunks: 2 operands x 2 buffers x 16 x 132 floats = 33 KiB of LDS.
+constexpr int GK2 = 16;
+constexpr int GP2 = 132;               // LDS row pitch in floats (528 B: 16-byte aligned rows, rows 4 banks apart)
+
+__device__ __forceinline__ TileRegs tile_load128(const Operand &op, int64_t m0, int64_t M, int64_t k0, int64_t k_end) {
+    TileRegs t;
+    const int tid = threadIdx.x;
+    if (op.ms == 1) {                  // m-contiguous: thread = (k = tid / 16, 4 consecutive m at 4 * (tid % 16) [+64])
+        const int64_t k = k0 + (tid >> 4);
+        const bool vec_ok = ((op.ks & 3) == 0) && ((reinterpret_cast<uintptr_t>(op.p) & 15u) == 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int64_t m = m0 + (tid & 15) * 4 + 64 * h;
+            if (k < k_end && vec_ok && m + 4 <= M) t.v[h] = *reinterpret_cast<const f32x4 *>(op.p + k * op.ks + m);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) t.v[h][j] = (k < k_end && m + j < M) ? op.p[k * op.ks + m + j] : 0.0f;
+            }
+        }
+    } else if (op.ks == 1) {           // k-contiguous: thread = (m = tid / 4 [+64], 4 consecutive k at 4 * (tid % 4)): 4 lanes per row
+        const int64_t k = k0 + 4 * (tid & 3);
+        const bool vec_ok = ((op.ms & 3) == 0) && ((k0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(op.p) & 15u) == 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int64_t m = m0 + (tid >> 2) + 64 * h;
+            if (m < M && k + 4 <= k_end && vec_ok) t.v[h] = *reinterpret_cast<const f32x4 *>(op.p + m * op.ms + k);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) t.v[h][j] = (m < M && k + j < k_end) ? op.p[m * op.ms + k + j] : 0.0f;
+            }
+        }
+    } else {                           // neither: element (k, m) = (e / 128, e % 128), e = tid + 256 j
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + 256 * j;
+            const int64_t k = k0 + (e >> 7), m = m0 + (e & 127);
+            t.v[j >> 2][j & 3] = (k < k_end && m < M) ? op.p[k * op.ks + m * op.ms] : 0.0f;
+        }
+    }
+    return t;
+}
+__device__ __forceinline__ void tile_store128(const Operand &op, const TileRegs &t, float *lds) {
+    const int tid = threadIdx.x;
+    if (op.ms == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) *reinterpret_cast<f32x4 *>(&lds[(tid >> 4) * GP2 + (tid & 15) * 4 + 64 * h]) = t.v[h];
+    } else if (op.ks == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds[(4 * (tid & 3) + j) * GP2 + (tid >> 2) + 64 * h] = t.v[h][j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + 256 * j;
+            lds[(e >> 7) * GP2 + (e & 127)] = t.v[j >> 2][j & 3];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab,
+                                                      GemmEpilogue e) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][GK2 * GP2];     // [buffer][A | B]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int64_t bm0 = (int64_t)blockIdx.y * 128, bn0 = (int64_t)blockIdx.x * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int64_t k_begin = (int64_t)blockIdx.z * k_per_slab;
+    const int64_t k_end = (k_begin + k_per_slab < K) ? k_begin + k_per_slab : K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
+    // software pipeline: the next chunk's global loads are in flight while the MFMAs consume the current LDS buffer.  (Two
+    // chunks of register prefetch were tried: 221 VGPRs, one block per CU, 74 -> 112 us per launch on the SDXL mix.  The kernel
+    // is bound by the latency of the operand loads; more blocks per CU hide it better than a deeper pipeline in registers.)
+    TileRegs ra = tile_load128(A, bm0, M, k_begin, k_end), rb = tile_load128(B, bn0, N, k_begin, k_end);
+    tile_store128(A, ra, lds[0][0]);
+    tile_store128(B, rb, lds[0][1]);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k = k_begin; k < k_end; k += GK2) {
+        const bool more = k + GK2 < k_end;
+        if (more) { ra = tile_load128(A, bm0, M, k + GK2, k_end); rb = tile_load128(B, bn0, N, k + GK2, k_end); }
+        const float *la = lds[buf][0] + wm + i, *lb = lds[buf][1] + wn + i;
+#pragma unroll
+        for (int u = 0; u < GK2 / 2; u++) {
+            const float a0 = la[(2 * u + kk) * GP2], a1 = la[(2 * u + kk) * GP2 + 32];
+            const float b0 = lb[(2 * u + kk) * GP2], b1 = lb[(2 * u + kk) * GP2 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) { tile_store128(A, ra, lds[buf ^ 1][0]); tile_store128(B, rb, lds[buf ^ 1][1]); }
+        __syncthreads();
+        buf ^= 1;
+    }
+    float *c = C + (int64_t)blockIdx.z * M * N;
+    GemmEpilogue ee = e;
+    if (gridDim.z > 1) ee = GemmEpilogue{};                     // the epilogue then runs in gemm_reduce
+    bool bad = false;
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t row = bm0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * kk, col = bn0 + wn + 32 * tn + i;
+                if (row < M && col < N) gemm_store(ee, c, N, row, col, acc[tm][tn][r], bad);
+            }
     if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
@@ -292,6 +413,29 @@ int split_k_slabs(int64_t M, int64_t N, int64_t K) {
 }
 
 void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, float *slabs, const GemmEpilogue &e, hipStream_t s) {
+    if (M >= 256 && N >= 256) {
+        // 128 x 128 tiles; split K so that about two blocks per CU are resident (512 on 256 CUs; 256 and 1024 measured slower)
+        const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        int64_t z = 512 / tiles;
+        const int64_t zmax = (K + 127) / 128;
+        if (z > zmax) z = zmax;
+        while (z > 1 && (size_t)z * (size_t)M * (size_t)N > SLAB_FLOATS) z--;
+        if (z < 1) z = 1;
+        int64_t k_per = (K + z - 1) / z;
+        k_per = (k_per + GK2 - 1) / GK2 * GK2;                  // whole k-chunks per slab (keeps 16-byte loads along k aligned)
+        z = (K + k_per - 1) / k_per;
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)z), block(256);
+        if (z == 1) {
+            MECHA_LAUNCH(MK_ROT_GEMM, gemm128_kernel, grid, block, 0, s, A, B, C, M, N, K, k_per, e);
+        } else {
+            GemmEpilogue none{};
+            MECHA_LAUNCH(MK_ROT_GEMM, gemm128_kernel, grid, block, 0, s, A, B, slabs, M, N, K, k_per, none);
+            const int64_t total = M * N;
+            const unsigned rb = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+            MECHA_LAUNCH(MK_ROT_GEMM, gemm_reduce_kernel, dim3(rb), dim3(256), 0, s, slabs, (int)z, C, M, N, e);
+        }
+        return;
+    }
     const int z = split_k_slabs(M, N, K);
     int64_t k_per = (K + z - 1) / z;
     k_per = (k_per + 1) / 2 * 2;                                // the MFMA consumes k in pairs
@@ -410,10 +554,12 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
         // G2 = b G + c G G;  nxt = a cur + G2 cur
         GemmEpilogue mix{};
         mix.axpy = G; mix.axpy_a = ps.step[it].b; mix.axpy_b = ps.step[it].c;
-        gemm(Operand{G, 1, r}, Operand{G, r, 1}, G2, r, r, r, slabs, mix, s);
+        // (G and b G + c G G are symmetric bit for bit -- the same products in the same order on both sides of the diagonal --
+        //  so both operands are read along their rows: contiguous 16-byte loads)
+        gemm(Operand{G, r, 1}, Operand{G, r, 1}, G2, r, r, r, slabs, mix, s);
         GemmEpilogue upd{};
         upd.axpy = cur; upd.axpy_a = ps.step[it].a; upd.axpy_b = 1.0f;
-        gemm(Operand{G2, 1, r}, Operand{cur, c, 1}, nxt, r, c, r, slabs, upd, s);
+        gemm(Operand{G2, r, 1}, Operand{cur, c, 1}, nxt, r, c, r, slabs, upd, s);
         float *t = cur; cur = nxt; nxt = t;
     }
     if (iters_out) *iters_out += ps.n;
