@@ -344,6 +344,7 @@ def merge(
     omit_non_finite_inputs: bool = True,
     strict_mandatory_keys: bool = False,
     output=None,
+    threads: Optional[int] = None,
     cache: Optional[Dict[RecipeNode, Any]] = None,
     backend=None,
 ) -> Optional[MutableMapping[str, torch.Tensor]]:
@@ -353,7 +354,10 @@ def merge(
     byte budget of the pinned staging buffers (the reference's 2**28 read window scaled to a 288 GB device).
     Under ``torch.distributed`` every rank merges its own stripe of keys; with a file output all ranks fill the same
     file, with a dict output each rank returns its stripe.  ``cache``: {merge node: its method's ``create_cache()`` object}
-    (merging.py:199), handed to the node's body on every key; today ``rotate`` keeps its transforms there (svd.py:55-79)."""
+    (merging.py:199), handed to the node's body on every key; today ``rotate`` keeps its transforms there (svd.py:55-79).
+    ``threads`` (merging.py:59-62, :171-179): worker threads of the per-key path, each on its own HIP stream like the
+    reference's pool threads (merging.py:330-341); None = min(max(input files, 2), cpu count, 4), 0 = the caller's thread.
+    The fused batched path merges whole waves of keys per launch and does not use it."""
     if merge_dtype != torch.float32:
         raise NotImplementedError("the MI355X kernels compute in float32 (the reference default merge_dtype)")
     if not omit_non_finite_inputs:
@@ -422,8 +426,10 @@ def merge(
             _run_fused(plan, backend, readers, my_items, header, sink, to_file, output_device, output_dtype,
                        total_buffer_size, check_finite_output, skipped)
         else:
+            if threads is None:
+                threads = min(max(len(models), 2), os.cpu_count() or 1, 4)       # merging.py:171-172
             _run_generic(recipe, backend, readers, my_items, header, sink, to_file, output_device, output_dtype,
-                         check_finite_output, strict_mandatory_keys, skipped, cache or {})
+                         check_finite_output, strict_mandatory_keys, skipped, cache or {}, threads)
         for k in skipped:
             log.debug("Skipping key: %s", k)
 
@@ -682,7 +688,7 @@ class _null:
 
 # ------------------------------------------------------------------ generic (per key) path
 def _run_generic(recipe, backend, readers, items, header, sink, to_file, output_device, output_dtype, check_finite_output,
-                 strict_mandatory_keys, skipped, cache):
+                 strict_mandatory_keys, skipped, cache, threads=0):
     """KeyMergeVisitor (merging.py:374-482) for graphs the fuser does not cover: every model value is uploaded,
     cast to fp32 with the fused finite check, and the method bodies run per key on device tensors."""
     dev = backend.device
@@ -721,21 +727,51 @@ def _run_generic(recipe, backend, readers, items, header, sink, to_file, output_
             return node.merge_method.merge_key(args, kwargs, key, cache.get(node))
         raise TypeError(type(node))
 
-    for key, _ in items:
+    lock = threading.Lock()
+
+    def merge_one(key):
         meta = header[key]
         try:
             res = evaluate(recipe, key)
         except StateDictKeyError as e:
             if strict_mandatory_keys:
                 raise RuntimeError(f"Could not merge mandatory key: {e}") from e
-            skipped.append(key)
-            continue
+            with lock:
+                skipped.append(key)
+            return
         if not isinstance(res, torch.Tensor):
             res = torch.full(meta.shape, float(res), dtype=torch.float32, device=dev)
         if check_finite_output and res.numel() and not bool(torch.isfinite(res).all()):
             log.warning("There are non finite values in key '%s': %s", key, meta)
         res = res.to(output_dtype).reshape(meta.shape)
-        if to_file:
+        if not to_file:
+            res = res.to(output_device) if output_device is not None else res
+        if res.is_cuda:
+            torch.cuda.current_stream(res.device).synchronize()                # the sink may read it from another stream / the host
+        with lock:
             sink[key] = res
-        else:
-            sink[key] = res.to(output_device) if output_device is not None else res
+
+    if threads and threads > 0 and dev.type == "cuda" and len(items) > 1:
+        # keys are independent (merging.py:223-229): pool threads, each inside its own HIP stream (merging.py:330-341), overlap
+        # the latency-bound work of different keys (rotate's chains of small GEMMs: 5.9 s -> 3.4 s for SDXL on 4 streams)
+        local = threading.local()
+
+        def task(key):
+            if not hasattr(local, "stream"):
+                local.stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.device(dev), torch.cuda.stream(local.stream):
+                merge_one(key)
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as pool:
+            futures = [pool.submit(task, key) for key, _ in items]
+            done, pending = concurrent.futures.wait(futures, return_when=concurrent.futures.FIRST_EXCEPTION)   # merging.py:354-371
+            for f in pending:
+                f.cancel()
+            for f in done:
+                f.result()
+            for f in pending:
+                if not f.cancelled():
+                    f.result()
+    else:
+        for key, _ in items:
+            merge_one(key)

@@ -94,3 +94,31 @@ def test_pipeline_many_waves_medium_checkpoint(tmp_path):
         f32 = [O.to_f32(t[k].view(torch.int16).numpy().view(np.uint16), "bfloat16") for t in ins]
         want = O.from_f32(O.add_difference_ties(f32[0], f32[1:], k=0.2, alpha=1.0), "bfloat16")
         assert np.array_equal(many[k].view(torch.int16).numpy().view(np.uint16), want), k
+
+
+def test_generic_path_threads_match_the_callers_thread(toy_models, tmp_path):     # noqa: F811
+    """merge(threads=N): pool threads, each inside its own HIP stream (reference merging.py:171-179, :330-341), give the
+    same tensors as threads=0, to a dict and to a file; a failing key still raises."""
+    import safetensors.torch
+    import sd_mecha_amd as amd
+    m = [amd.model(p) for p in toy_models]
+    kw = dict(merge_device="cuda", output_dtype=torch.bfloat16)
+    recipe = amd.rotate(m[0], m[1], alignment=1.0, alpha=0.0)
+    want = amd.merge(recipe, threads=0, **kw)
+    got = amd.merge(recipe, threads=4, **kw)
+    assert set(got) == set(want)
+    for k in want:
+        if k != "__metadata__":
+            assert torch.equal(got[k], want[k]), k
+    out = tmp_path / "rot.safetensors"
+    amd.merge(recipe, threads=3, output=out, **kw)
+    loaded = safetensors.torch.load_file(str(out))
+    for k in want:
+        if k != "__metadata__":
+            assert torch.equal(loaded[k], want[k].cpu()), k
+
+    @amd.merge_method(register=False)
+    def boom(a, b, **kwargs):
+        raise ValueError("no")
+    with pytest.raises(ValueError):
+        amd.merge(boom(m[0], m[1]), threads=2, **kw)

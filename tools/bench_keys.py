@@ -42,8 +42,54 @@ def run_rotate(args, device):
     keys = eligible(load_manifest("sdxl-sgm"))
     keys.sort(key=lambda kv: -numel(kv[1]))
     keys = keys[::args.key_stride]
-    gen = torch.Generator(device=device).manual_seed(7)
     sweeps_all, done_bytes, flops, skipped = [], 0, 0, 0
+    if args.threads > 1:
+        # keys are independent and a key never synchronises with the host inside the Procrustes solve: worker threads, each on
+        # its own HIP stream, overlap the latency-bound small GEMMs of different keys (the reference's executor does the same
+        # with a torch.cuda.Stream per pool thread, merging.py:171-179, :330-341).  Inputs are made up front.
+        import concurrent.futures
+        import threading
+        gen = torch.Generator(device=device).manual_seed(7)
+        data = []
+        for k, shape in keys:
+            a = torch.empty(shape, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
+            b = torch.empty(shape, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
+            data.append((shape, a, b))
+        torch.cuda.synchronize()
+        local = threading.local()
+
+        def work(item):
+            shape, a, b = item
+            if not hasattr(local, "stream"):
+                local.stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(local.stream):
+                out, sweeps = mm.rotate(a, b, alignment=1.0, alpha=0.0, out_dtype=torch.bfloat16, return_sweeps=True)
+                local.stream.synchronize()
+            return shape, sweeps
+
+        t0 = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(max_workers=args.threads) as pool:
+            results = list(pool.map(work, data))
+        torch.cuda.synchronize()
+        t_total = time.perf_counter() - t0
+        for shape, sweeps in results:
+            n, p = mm.rotate_shape_2d(shape)
+            sweeps_all.append(sweeps)
+            done_bytes += numel(shape) * 2 * 3
+            flops += rotate_flops(n, p, sweeps)
+        return {
+            "metric": "merged state-dict GB/s", "value": round(done_bytes / t_total / 1e9, 3), "unit": "GB/s", "n_gpus": 1,
+            "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "sdxl_rotate", "description": "SDXL svd.rotate(a, b, alignment=1.0, alpha=0.0) per >=2-D key of 2 random-init bf16 checkpoints, bf16 out",
+                       "keys": len(sweeps_all), "key_stride": args.key_stride, "threads": args.threads, "streams": args.threads},
+            "seconds": round(t_total, 3), "keys_per_second": round(len(sweeps_all) / t_total, 2),
+            "roofline": {"bound": "mfma", "kernel": "rotate_gemm_f32mfma", "achieved": round(flops / t_total / 1e12, 2),
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / t_total / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "algorithmic_flops": flops,
+                         "note": "achieved = algorithmic GEMM flops over WALL time of the whole job (kernels of several keys overlap: no per-kernel timers)"},
+            "newton_schulz": {"iterations_mean": round(sum(sweeps_all) / max(len(sweeps_all), 1), 2), "iterations_max": max(sweeps_all, default=0)},
+        }
+    gen = torch.Generator(device=device).manual_seed(7)
     torch.cuda.synchronize()
     _lib.profile_enable(True)
     t_total = 0.0
@@ -147,6 +193,7 @@ def main():
     ap.add_argument("--key-stride", type=int, default=1, help="take every n-th eligible key (largest first for rotate)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--threads", type=int, default=1, help="sdxl_rotate: worker threads, each with its own HIP stream")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "needs a GPU"
     device = torch.device("cuda", 0)
