@@ -310,7 +310,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, i
     const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
     TileCursor cur;
     uint32_t lo[CAP], width[CAP], shift[CAP], low_mask[CAP];
-    uint32_t below[CAP];                           // per wave (uniform): elements with |delta| < lo
+    uint32_t below[CAP];                           // per lane: elements with |delta| < lo
     bool active[CAP];
 #pragma unroll
     for (int d = 0; d < CAP; d++) { below[d] = 0; active[d] = false; lo[d] = width[d] = shift[d] = low_mask[d] = 0; }
@@ -318,7 +318,12 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, i
     auto flush = [&](int s) {
 #pragma unroll
         for (int d = 0; d < CAP; d++) {
-            if (d < nd && active[d] && below[d] && (threadIdx.x & 63) == 0) atomicAdd(&lds_cnt[2 * d], below[d]);
+            if (d < nd && active[d]) {                                   // block-uniform
+                uint32_t tot = below[d];                                 // per lane: sum over the wave
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+                if (tot && (threadIdx.x & 63) == 0) atomicAdd(&lds_cnt[2 * d], tot);
+            }
             below[d] = 0;
         }
         __syncthreads();
@@ -360,27 +365,34 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, i
         for (int d = 0; d < CAP; d++) any |= (d < nd) && active[d];
         if (!any) continue;                                          // every pair of this key was solved by the sample
         const mecha_segment seg = cur.seg;
-#pragma unroll 1
+        // the loads of BOTH vector positions of the tile are issued before the first one is consumed (pairs the sample already
+        // solved are loaded too: they are rare): twice the bytes in flight per wave
+        int valid_u[2];
+        Raw8<W32> rb_u[2], rv_u[2][CAP];
+#pragma unroll
         for (int u = 0; u < 2; u++) {
             const int64_t local = (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
-            if (local >= seg.numel) continue;
-            const int valid = (seg.numel - local >= 8) ? 8 : (int)(seg.numel - local);
-            const bool vec = p.vec_ok && valid == 8;
+            valid_u[u] = (local >= seg.numel) ? 0 : ((seg.numel - local >= 8) ? 8 : (int)(seg.numel - local));
+            if (valid_u[u] == 0) continue;
+            const bool vec = p.vec_ok && valid_u[u] == 8;
             const int64_t e = seg.offset + local;
-            // every load of this position first (pairs the sample already solved are loaded too: they are rare)
-            Raw8<W32> rb, rv[CAP];
-            if (p.base != nullptr) rb = load_raw<W32>(vec, p.base, e, valid);
+            if (p.base != nullptr) rb_u[u] = load_raw<W32>(vec, p.base, e, valid_u[u]);
 #pragma unroll
             for (int d = 0; d < CAP; d++)
-                if (d < nd) rv[d] = load_raw<W32>(vec, p.in[d0 + d], e, valid);
+                if (d < nd) rv_u[u][d] = load_raw<W32>(vec, p.in[d0 + d], e, valid_u[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int valid = valid_u[u];
+            if (valid == 0) continue;
             float b[8];
-            if (p.base != nullptr) unpack_raw<W32>(p.in_dt, rb, b);
+            if (p.base != nullptr) unpack_raw<W32>(p.in_dt, rb_u[u], b);
             const bool ragged = __ballot(valid < 8) != 0ull;               // wave-uniform: some lane is at the end of the key
 #pragma unroll
             for (int d = 0; d < CAP; d++) {
                 if (d < nd && active[d]) {
                     float v[8];
-                    unpack_raw<W32>(p.in_dt, rv[d], v);
+                    unpack_raw<W32>(p.in_dt, rv_u[u][d], v);
                     if (p.base != nullptr) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];                     // subtract (linear.py:101)
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, i
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         const uint32_t tt = (__float_as_uint(v[j]) & 0x7fffffffu) - lo[d];     // |delta| pattern relative to lo
-                        below[d] += (uint32_t)__popcll(__ballot((int)tt < 0));
+                        below[d] += tt >> 31;                                                  // 1 iff |delta| < lo (per lane; summed over the wave at the flush)
                         // branch-free: values outside the bracket (92% of them) add to a per-lane dump word instead
                         const uint32_t bin = d * TIES_BINS + bracket_bin(tt, shift[d], low_mask[d]);
                         atomicAdd(&lds_hist[tt <= width[d] ? bin : dump], 1u);
