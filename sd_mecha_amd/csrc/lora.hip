@@ -200,7 +200,10 @@ typedef __attribute__((address_space(1))) const unsigned char global_byte;
 // compiler does not know about only make its own waits conservative (vmcnt retires in order).
 __device__ __forceinline__ void glds16(const char *src, unsigned char *dst) {
     const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte *)dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds), "v"(src) : "memory", "m0");
+    // M0 is compiler-reserved and not preserved around an asm statement: written in the statement that reads it, and put back
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
 }
 
 template <int LDT>
