@@ -366,14 +366,11 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
         // the key is entered): sum_i fma(delta_i * s, w, .) and fma((sum_i delta_i) * s, w, .) differ by fp32 rounding of the
         // partial sums only, inside the parity bar of this method (BLAS-ordered sgemm in the reference: <= 1 ulp of the output
         // dtype).  A fold per rank-32 network cost as many instructions as its four MFMAs.
-        if (now.k0 == 0 && (net.reserved & NET_STARTS_GROUP)) {           // the chain starts from C = 0 (an inline constant: no register clears)
-            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        // The chain always accumulates; the accumulators are cleared where a group ends (below) and at the start of the tile.
+        // (Starting a group with C = 0 as an inline constant in one branch and accumulating in the other made the compiler
+        // keep two register sets for the accumulators: 16 v_mov_b64 behind an s_nop 10 in EVERY round, between the MFMA pairs.)
 #pragma unroll
-            for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[0], b[0][rg], zero);
-        } else {
-#pragma unroll
-            for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[0], b[0][rg], acc[rg]);
-        }
+        for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[0], b[0][rg], acc[rg]);
 #pragma unroll
         for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[1], b[1][rg], acc[rg]);
         if (check_down)                                                   // this thread's 16 bytes of the down slab
@@ -400,6 +397,10 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
 #pragma unroll
                     for (int i = 0; i < 16; i++) total[rg][i] = __builtin_fmaf(acc[rg][i] * scale, weight, total[rg][i]);
             }
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[rg][i] = 0.0f;
         }
         done++;
     };
