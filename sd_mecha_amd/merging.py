@@ -486,8 +486,9 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
     in_dtype = readers[id(plan.models[0])].meta(items[0][0]).dtype if items else torch.float16
     n_models = len(plan.models)
     in_esz, out_esz = DTYPE_REVERSE_MAPPING[in_dtype][1], DTYPE_REVERSE_MAPPING[output_dtype][1]
-    # two buffer sets (double buffering), each holding n_models inputs + 1 output
-    per_set = max(total_buffer_size // 2, 1 << 20)
+    # buffer sets (2 = double buffering), each holding n_models inputs + 1 output; the budget is shared between them
+    n_sets = max(1, int(os.environ.get("MECHA_BUFFER_SETS", "2")))
+    per_set = max(total_buffer_size // n_sets, 1 << 20)
     wave_elems = max(per_set // (n_models * in_esz + out_esz), 1024)
     waves = _plan_waves(items, wave_elems)
     if not waves:
@@ -506,7 +507,7 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
         }
     last_stats.clear()
     with _phase("alloc"):
-        sets = [alloc_set(), alloc_set()] if len(waves) > 1 else [alloc_set()]
+        sets = [alloc_set() for _ in range(min(n_sets, len(waves)))]
     s_copy_in = backend.stream() if is_cuda else None
     s_comp = backend.stream() if is_cuda else None
     s_copy_out = backend.stream() if is_cuda else None
