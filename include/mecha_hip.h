@@ -194,6 +194,9 @@ int mecha_dare_draw_masks_host(uint64_t seed, float probability, int n_models, i
  * `lora_dtype` (MECHA_F16 or MECHA_BF16: the MFMA path multiplies 16-bit operands exactly, accumulates in fp32).
  * scales[i] = alpha_i / r_i (compose_alpha, lycoris.py:258-263) or 1 (compose); weights[i] = the add_difference alpha
  * (a network with weight == 0 is skipped, linear.py:72-73).  base == NULL computes the (sum of) deltas only.
+ * Consecutive networks with bit-equal (scale, weight) are accumulated in one fp32 MFMA chain and folded once:
+ * fma((sum_i up_i @ down_i) * scale, weight, out) -- against a fold per network this moves results by fp32 rounding of the
+ * partial sums only (the reference's product is BLAS-ordered: parity is <= 1 ulp of the output dtype).
  * ups / downs / ranks / scales / weights are HOST arrays of n_networks entries (<= MECHA_MAX_MODELS). */
 int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t cols, int base_dtype, int out_dtype,
                           const void *const *ups, const void *const *downs, const int32_t *ranks, const float *scales,
@@ -232,11 +235,13 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
  * n_rows x n_cols (svd.py:49-53): centre both matrices by their column means * centralization (svd.py:67-70),
  * orthogonal_procrustes (svd.py:157-169; FullRankOrthogonalMatmul :194-206 for n_rows >= n_cols, LowRankOrthogonalMatmul
  * :172-191 otherwise) with every contraction on f32 MFMA; U V^T of the reference's SVD is computed as the orthogonal
- * polar factor by Newton-Schulz iterations (GEMMs only, no SVD); apply the transform to the centred `a`, add b's mean
- * (svd.py:84-85).  The early-outs of svd.py:37-47 stay in the host shim (mecha_allclose_half implements the
- * torch.allclose(a.half(), b.half()) test of :46).
- * SYNCHRONISES `stream` once per iteration (it reads the convergence measure).  `sweeps_out` (HOST int, may be NULL)
- * receives the number of Newton-Schulz iterations (summed over the key's polar solves: 1 for tall, 2 for wide keys). */
+ * polar factor by a fixed schedule of 14 odd-quintic iteration steps (GEMMs only, no SVD; the optimal composition from
+ * [1e-7, 1], DESIGN.md "rotate"); apply the transform to the centred `a`, add b's mean (svd.py:84-85).  The early-outs of
+ * svd.py:37-47 stay in the host shim (mecha_allclose_half implements the torch.allclose(a.half(), b.half()) test of :46).
+ * Only enqueues on `stream`: nothing is read back, keys on different streams overlap.  A singular value below 1e-7 of
+ * the largest (a centred square key has one) ends between 0 and 1 instead of LAPACK's noise-determined +-1.
+ * `sweeps_out` (HOST int, may be NULL) receives the number of iteration steps (14 per polar solve: 1 solve for tall,
+ * 2 for wide keys; 0 when `transform_in` is given). */
 size_t mecha_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols);
 int mecha_rotate(const void *a, const void *b, void *out, int64_t n_rows, int64_t n_cols, int in_dtype, int out_dtype,
                  float centralization, void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);
