@@ -33,6 +33,8 @@ WORKLOADS = {
     # BASELINE config 5: one base (kohya key naming) + 16 kohya LoRA files, rank 32, fp16, alpha 16, weight 1.0
     "sdxl_lora": ("sdxl-kohya", None, 1, "lora"),
     # BASELINE config 3, one GPU's share: stripe 0 of the 8 key stripes (LPT) of the FLUX-dev diffuser, 8 checkpoints
+    # BASELINE config 4: svd.rotate of model A onto B, every key through the per-key path (merge(threads=...))
+    "sdxl_rotate": ("sdxl-sgm", None, 2, "rotate"),
     "flux_navg": ("flux-flux", ("diffuser",), 8, "navg"),
     "flux_ties": ("flux-flux", ("diffuser",), 8, "ties"),
 }
@@ -90,6 +92,7 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/mecha_e2e")
     ap.add_argument("--buffer-gib", type=float, default=16.0, help="total_buffer_size of merge() (pinned staging budget)")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--threads", type=int, default=None, help="merge(threads=...): worker threads of the per-key path (sdxl_rotate)")
     ap.add_argument("--sink", default="file", choices=["file", "none"],
                     help="file: one .safetensors on --dir; none: results come back to pinned host memory and are dropped "
                          "(the host-link pipeline alone: files -> staging -> H2D -> kernels -> D2H)")
@@ -126,6 +129,8 @@ def main():
         elif recipe_kind == "ties":
             deltas = [amd.subtract(m, models[0]) for m in models[1:]]
             recipe = amd.add_difference(models[0], amd.ties_sum(*deltas, k=0.2), alpha=1.0) | models[0]
+        elif recipe_kind == "rotate":
+            recipe = amd.rotate(models[0], models[1], alignment=1.0, alpha=0.0)
         elif recipe_kind == "navg":
             recipe = amd.n_average(*models)
         else:
@@ -141,14 +146,14 @@ def main():
             t0 = time.perf_counter()
             from sd_mecha_amd import merging
             amd.merge(recipe, output=str(out) if args.sink == "file" else merging.NullSink(), output_dtype=torch.bfloat16,
-                      total_buffer_size=int(args.buffer_gib * 2 ** 30))
+                      total_buffer_size=int(args.buffer_gib * 2 ** 30), threads=args.threads)
             times.append(time.perf_counter() - t0)
             print("phases (host seconds):", {k: round(v, 3) for k, v in merging.last_stats.items()}, file=sys.stderr, flush=True)
         best = min(times)
         line = {
             "metric": "merged state-dict GB/s, end to end (files on tmpfs -> file on tmpfs)" if args.sink == "file" else
                       "merged state-dict GB/s, host-link pipeline (files on tmpfs -> pinned staging -> H2D -> kernels -> D2H -> pinned, no output file)",
-            "workload": args.workload, "sink": args.sink,
+            "workload": args.workload, "sink": args.sink, "threads": args.threads,
             "value": round(moved / best / 1e9, 2), "unit": "GB/s", "seconds": [round(t, 3) for t in times],
             "bytes_moved": moved, "elements": elems, "keys": len(manifest), "n_models": n_models,
             "total_buffer_size_gib": args.buffer_gib, "host_link_GBs": link_rate(device),
