@@ -114,9 +114,6 @@ __device__ __forceinline__ void cursor_seek(const TiesParams &p, long long t, Ti
 
 // 8 consecutive elements as fp32, dtype chosen at run time (wave-uniform).
 __device__ __forceinline__ void load_rt(int dt, bool vec, const void *ptr, int64_t e, int valid, float (&v)[8]) {
-#ifdef TIES_EXPERIMENT_STATIC_BF16
-    dt = MECHA_BF16; vec = true;
-#endif
     if (vec) {
         if (dt == MECHA_BF16) load8<MECHA_BF16, true>(ptr, e, v);      // streamed: far larger than any cache between passes
         else if (dt == MECHA_F16) load8<MECHA_F16, true>(ptr, e, v);
@@ -180,9 +177,6 @@ __device__ __forceinline__ void store1_rt(int dt, void *ptr, int64_t e, float v)
     else store1<MECHA_F32>(ptr, e, v);
 }
 __device__ __forceinline__ void store_rt(int dt, bool vec, void *ptr, int64_t e, int valid, const float (&v)[8]) {
-#ifdef TIES_EXPERIMENT_STATIC_BF16
-    dt = MECHA_BF16; vec = true;
-#endif
     if (vec) {
         if (dt == MECHA_BF16) store8<MECHA_BF16, true>(ptr, e, v);
         else if (dt == MECHA_F16) store8<MECHA_F16, true>(ptr, e, v);
@@ -517,7 +511,7 @@ __global__ __launch_bounds__(1024) void ties_amb_offsets_kernel(TiesParams p, in
 
 // ------------------------------------------------------------------------------------------------ B: hist / scan
 template <int PASS> struct PassCfg;
-template <> struct PassCfg<1> { static constexpr int shift = 20, bins = 2048; static constexpr uint32_t prefix_mask = 0u; };
+template <> struct PassCfg<1> { static constexpr int shift = 20, bins = 2048; [[maybe_unused]] static constexpr uint32_t prefix_mask = 0u; };
 template <> struct PassCfg<2> { static constexpr int shift = 9, bins = 2048; static constexpr uint32_t prefix_mask = 0x7ff00000u; };
 template <> struct PassCfg<3> { static constexpr int shift = 0, bins = 512; static constexpr uint32_t prefix_mask = 0x7ffffe00u; };
 

@@ -95,9 +95,6 @@ def run_rotate(args, device):
     t_total = 0.0
     for k, shape in keys:
         n, p = mm.rotate_shape_2d(shape)
-        if False:
-            skipped += 1
-            continue
         a = torch.empty(shape, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
         b = torch.empty(shape, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
         torch.cuda.synchronize()
