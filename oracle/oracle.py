@@ -241,11 +241,16 @@ def add_difference_ties(base, models: Sequence[np.ndarray], k: float = 0.2, alph
 
 
 # ----------------------------------------------------------------- DARE
+TORCH_DEFAULT_SEED = 67280421310721   # a torch.Generator that was never seeded: what ties.py:29-31 uses for seed None / < 0
+
+
 def dare_masks(seed: int, probability: float, n_models: int, shape) -> np.ndarray:
     """ties.py:29-33, :63-64 with della_eps == 0: torch CPU generator stream, one draw per element,
     deltas in order.  Returns uint8 [n_models, *shape] keep masks."""
     n = int(np.prod(shape, dtype=np.int64))
     masks = np.empty((n_models, n), dtype=np.uint8)
+    if seed is None or seed < 0:
+        seed = TORCH_DEFAULT_SEED
     lib().orc_dare_masks(int(seed) & 0xFFFFFFFFFFFFFFFF, float(np.float32(probability)), n_models, n, _p(masks))
     return masks.reshape((n_models,) + tuple(shape))
 
@@ -307,8 +312,6 @@ def ties_sum_with_dropout(deltas: Sequence[np.ndarray], probability: float = 0.9
         return 0
     ds = [_f32(d) for d in deltas]
     if masks is None:
-        if seed is None or seed < 0:
-            raise ValueError("the oracle needs an explicit seed >= 0 (an unseeded torch generator is not reproducible)")
         masks = dare_masks(seed, probability, len(ds), ds[0].shape)
     dropped = []
     for d, m in zip(ds, masks):

@@ -10,6 +10,10 @@ import collections as _collections
 from . import merge_methods as _mm
 from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError, dare_draw_masks  # noqa: F401
 from .recipe_nodes import (  # noqa: F401
+    Parameter,
+    RealizedKeyRelation,
+    Return,
+    StateDict,
     LiteralRecipeNode,
     MergeMethod,
     MergeRecipeNode,
@@ -23,16 +27,28 @@ from .recipe_nodes import (  # noqa: F401
 )
 
 
-def _fallback(a, default, **kwargs):
-    """fallback (logistics.py:12-35): resolved by the executor (first input that has the key)."""
-    return a if a is not None else default
+class _fallback:
+    """fallback (logistics.py:12-35): the first of (`a`, `default`) -- in the order the key analysis stored in
+    ``key_relation.meta`` -- whose value for the key can be produced."""
+
+    def __call__(self, a, default, **kwargs):
+        (key,), _ = relation = kwargs["key_relation"]
+        candidates = {"a": a, "default": default}
+        for param in relation.meta:
+            try:
+                return candidates[param][key]
+            except StateDictKeyError:
+                continue
+        raise StateDictKeyError(key)
 
 
-weighted_sum = merge_method(_mm.weighted_sum)
-n_average = merge_method(_mm.n_average)
-add_difference = merge_method(_mm.add_difference)
+# `lazy`: parameters the reference declares as Parameter(StateDict[...]) (linear.py:8-9, :27, :65-66, :80; svd.py:11-12;
+# logistics.py:23-24): the executor hands them over as lazy mappings, so `alpha == 0` never loads `b` (merging.py:579-589)
+weighted_sum = merge_method(_mm.weighted_sum, lazy=("a", "b"))
+n_average = merge_method(_mm.n_average, lazy=("models",))
+add_difference = merge_method(_mm.add_difference, lazy=("a", "b"))
 subtract = merge_method(_mm.subtract)
-scale = merge_method(_mm.scale)
+scale = merge_method(_mm.scale, lazy=("a",))
 slerp = merge_method(_mm.slerp)
 perpendicular_component = merge_method(_mm.perpendicular_component)
 add_perpendicular = merge_method(_mm.add_perpendicular)
@@ -40,10 +56,10 @@ ties_sum = merge_method(_mm.ties_sum)
 ties_sum_extended = merge_method(_mm.ties_sum_extended)
 ties_sum_with_dropout = merge_method(_mm.ties_sum_with_dropout)
 add_difference_ties = merge_method(_mm.add_difference_ties)
-cast = merge_method(_mm.cast)
-omit_non_finite = merge_method(_mm.omit_non_finite)
-fallback = merge_method(_fallback, identifier="fallback")
-rotate = merge_method(_mm.rotate, cache_factory=lambda: _collections.defaultdict(dict))   # svd.py:10
+cast = merge_method(_mm.cast, reuse_outputs=False)
+omit_non_finite = merge_method(_mm.omit_non_finite, reuse_outputs=False)
+fallback = merge_method(_fallback, identifier="fallback", lazy=("a", "default"), reuse_outputs=False)
+rotate = merge_method(_mm.rotate, lazy=("a", "b"), cache_factory=lambda: _collections.defaultdict(dict))   # svd.py:10
 lora_merge = merge_method(_mm.lora_merge)
 lora_delta = merge_method(_mm.lora_delta)
 

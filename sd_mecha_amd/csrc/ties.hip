@@ -1456,7 +1456,8 @@ int run_ties(const TiesCall &c) {
     MECHA_REQUIRE(c.inputs != nullptr && c.n_deltas >= 1 && c.n_deltas <= TIES_MAX_DELTAS - (c.base ? 1 : 0),
                   "TIES needs 1..%d deltas (got %d)", TIES_MAX_DELTAS - (c.base ? 1 : 0), c.n_deltas);
     MECHA_REQUIRE(mecha_valid_dtype(c.in_dt) && mecha_valid_dtype(c.out_dt), "unknown dtype code (in %d, out %d)", c.in_dt, c.out_dt);
-    MECHA_REQUIRE(c.k >= 0.0 && c.k <= 1.0, "k must be in [0, 1] (got %g): torch.kthvalue would raise", c.k);
+    // k > 1 is legal: kth = max(int((1 - k) * numel), 1) clamps the rank to 1 (ties.py:129); k < 0 asks for a rank beyond numel
+    MECHA_REQUIRE(c.k >= 0.0, "k must be >= 0 (got %g): the rank would exceed numel and torch.kthvalue would raise", c.k);
     const bool batched = c.segs_dev != nullptr;
     long long total_tiles = 0;
     int64_t max_numel = 0, sum_numel = 0;

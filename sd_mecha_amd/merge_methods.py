@@ -283,10 +283,11 @@ def ties_sum(*models, k: float = 1.0, vote_sgn: bool = False, out_dtype=None, fl
     return (out, thr) if return_thresholds else out
 
 
-def add_difference_ties(base, *models, k: float = 0.2, alpha=1.0, vote_sgn: bool = False, key=None, out_dtype=None,
+def add_difference_ties(base, *models, k: float = 1.0, alpha=1.0, vote_sgn: bool = False, key=None, out_dtype=None,
                         flags=None, check_finite=True, return_thresholds: bool = False):
     """The recipe of wrappers.py:70-94 fused into one pipeline:
-    add_difference(base, ties_sum(m_0 - base, ..., k), alpha).  Reads bf16/fp16 inputs directly."""
+    add_difference(base, ties_sum(m_0 - base, ..., k), alpha).  Reads bf16/fp16 inputs directly.  Defaults are the
+    wrapper's (wrappers.py:70-75): k = 1.0 keeps every delta element, alpha = 1.0."""
     al = _alpha(alpha)
     if math.isclose(al, 0.0) or not models:
         r = cast(base, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
@@ -318,6 +319,16 @@ def dare_draw_masks(seed: int, probability: float, n_models: int, numel: int, de
     _lib.check(_lib.lib().mecha_dare_draw_masks_host(int(seed) & 0xFFFFFFFFFFFFFFFF, float(probability), n_models, numel, host.data_ptr()),
                "mecha_dare_draw_masks_host")
     return host.to(device, non_blocking=False)
+
+
+# torch.Generator()'s state before any manual_seed: the reference creates a fresh generator per key and seeds it only for
+# seed >= 0 (ties.py:29-31), so seed=None draws the SAME masks every time, those of torch's default seed.  The caller's global
+# RNG is never touched.
+_TORCH_DEFAULT_SEED = 67280421310721
+
+
+def _dare_seed(seed) -> int:
+    return _TORCH_DEFAULT_SEED if seed is None or seed < 0 else int(seed)
 
 
 def _ties_extended(ds, keep_bits, k, vote_sgn, model_stock, cos_eps, probability, rescale, out_dtype, flags, check_finite,
@@ -384,14 +395,11 @@ def ties_sum_with_dropout(*deltas, probability=0.9, della_eps: float = 0.0, resc
         return ds[0]
     n, numel = len(ds), ds[0].numel()
     if not apply_stock:
-        if seed is None or seed < 0:
-            seed = int(torch.seed() & 0xFFFFFFFF)
+        seed = _dare_seed(seed)
         bits = keep_bits if keep_bits is not None else dare_draw_masks(seed, p, n, numel, ds[0].device)
         return _ties_extended(ds, bits, k, vote_sgn, True, cos_eps, p, rescale, out_dtype, flags, check_finite)
     if keep_bits is None:
-        if seed is None or seed < 0:
-            seed = int(torch.seed() & 0xFFFFFFFF)          # unseeded generator (ties.py:29-31)
-        keep_bits = dare_draw_masks(seed, p, n, numel, ds[0].device)
+        keep_bits = dare_draw_masks(_dare_seed(seed), p, n, numel, ds[0].device)
     if keep_bits.dtype != torch.int32 or tuple(keep_bits.shape) != (n, (numel + 31) // 32) or keep_bits.device != ds[0].device:
         raise ValueError("keep_bits must be int32 [n_models, ceil(numel/32)] on the deltas' device")
     keep_bits = _c(keep_bits)

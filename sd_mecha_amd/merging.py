@@ -39,7 +39,7 @@ from . import merge_methods as mm
 from . import model_configs
 from .arena import ArenaLayout, plan_arena, shard_keys_lpt
 from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError
-from .recipe_nodes import LiteralRecipeNode, MergeRecipeNode, ModelRecipeNode, RecipeNode, serialize, value_to_node
+from .recipe_nodes import LiteralRecipeNode, MergeRecipeNode, ModelRecipeNode, RealizedKeyRelation, RecipeNode, serialize, value_to_node
 from .streaming import DTYPE_REVERSE_MAPPING, InSafetensorsDict, OutSafetensorsDict, TensorMetadata, compact_holes, tensor_bytes
 
 _DT_CODE = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
@@ -114,7 +114,7 @@ def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
             if k is not None and models and len(models) < _lib.MAX_MODELS and not math.isclose(alpha, 0.0):
                 return FusedPlan("ties", [base] + models, {"k": k, "alpha": alpha, "vote_sgn": vote}, fallback)
     if ident == "add_difference_ties":
-        k = _scalar(recipe.kwargs.get("k"), 0.2) if "k" in recipe.kwargs else 0.2
+        k = _scalar(recipe.kwargs.get("k"), 1.0) if "k" in recipe.kwargs else 1.0          # wrappers.py:70-75
         alpha = _scalar(recipe.kwargs.get("alpha"), 1.0) if "alpha" in recipe.kwargs else 1.0
         vote = recipe.kwargs.get("vote_sgn")
         vote = bool(vote.value) if isinstance(vote, LiteralRecipeNode) else False
@@ -233,6 +233,80 @@ class _LoraStore:
             if n:
                 out.append((index, off, rows, cols, nets))
         return out, skip
+
+
+class GraphInfo:
+    """What the reference's graph finalization hands the executor, in the minimal structural form this backend uses
+    (graph_finalization.py:113-141 ``finalize_with_keys``: per node, the keys it can produce): a model produces the keys
+    its file holds, ``fallback`` the union of its two inputs (logistics.py:15-19), ``convert(lora, base)`` the keys of
+    ``base`` the LoRA file holds a network for, any other method the keys every tensor input can produce with one shape.
+    Also: how many consumers each node has (merge_context.py:45-61 -- a node with several is computed once per key) and
+    one instance per node of a class-based method (merge_context.py:94, :134)."""
+
+    def __init__(self, recipe: RecipeNode, readers):
+        self.readers = readers
+        self._keys: Dict[int, Optional[Dict[str, tuple]]] = {}
+        self.consumers: Dict[int, int] = {}
+        self.depth: Dict[int, int] = {}
+        self.instances: Dict[int, Any] = {}
+        self._count(recipe)
+        self.consumers[id(recipe)] = self.consumers.get(id(recipe), 0) + 1
+
+    def _count(self, node: RecipeNode) -> int:
+        """consumer counts + ModelDepthRecipeVisitor (recipe_nodes.py:334-349)."""
+        if id(node) in self.depth:
+            return self.depth[id(node)]
+        d = 0
+        if isinstance(node, ModelRecipeNode):
+            d = 1
+        elif isinstance(node, MergeRecipeNode):
+            self.instances[id(node)] = node.merge_method.instantiate()
+            for child in (*node.args, *node.kwargs.values()):
+                self.consumers[id(child)] = self.consumers.get(id(child), 0) + 1
+                d = max(d, self._count(child))
+            d += 1
+        self.depth[id(node)] = d
+        return d
+
+    def keys(self, node: RecipeNode) -> Optional[Dict[str, tuple]]:
+        """{key: shape} in production order, or None for a node that has a value for every key (scalar literals)."""
+        nid = id(node)
+        if nid in self._keys:
+            return self._keys[nid]
+        out: Optional[Dict[str, tuple]]
+        if isinstance(node, ModelRecipeNode):
+            out = {k: m.shape for k, m in self.readers[nid].metadata()}
+        elif isinstance(node, LiteralRecipeNode):
+            out = None
+            if isinstance(node.value, Mapping):
+                out = {k: (tuple(v.shape) if isinstance(v, torch.Tensor) else ()) for k, v in node.value.items()}
+        elif isinstance(node, MergeRecipeNode):
+            ident = node.merge_method.identifier
+            inputs = [self.keys(a) for a in (*node.args, *node.kwargs.values())]
+            if ident == "fallback":
+                out = {}
+                for ks in inputs:
+                    if ks is None:
+                        out = None
+                        break
+                    for k, shape in ks.items():
+                        out.setdefault(k, shape)
+            elif ident == "convert_lora_to_base":
+                lora_reader, base_reader = self.readers[id(node.args[0])], self.readers[id(node.args[1])]
+                out = {}
+                for k, m in base_reader.metadata():
+                    prefix = lora_mod.lora_key_prefix(k, m.shape, m.dtype.is_floating_point)
+                    if prefix is not None and f"{prefix}.{lora_mod.UP}" in lora_reader and f"{prefix}.{lora_mod.DOWN}" in lora_reader:
+                        out[k] = m.shape
+            else:
+                known = [ks for ks in inputs if ks is not None]
+                out = None
+                if known:
+                    out = {k: shape for k, shape in known[0].items() if all(ks.get(k) == shape for ks in known[1:])}
+        else:
+            raise TypeError(type(node))
+        self._keys[nid] = out
+        return out
 
 
 # ================================================================== compute backends
@@ -375,28 +449,34 @@ def merge(
     try:
         plan = fuse(recipe)
         recipe_text = serialize(recipe)
-        # structural key inference: keys every input of the merge holds with one shape (minimal)
-        # LoRA files name their tensors after the base keys (lora_<stem>.lora_up.weight ...): they take no part in key inference
+        # LoRA files name their tensors after the base keys (lora_<stem>.lora_up.weight ...): they take no part in config inference
         aux = _lora_file_nodes(recipe)
-        merge_inputs = plan.models if plan is not None else [m for m in models if id(m) not in aux]
+        merge_inputs = [m for m in models if id(m) not in aux]
         if not merge_inputs:
             raise ValueError("the recipe has no model inputs besides LoRA files")
         # model config: explicit (model(path, config=...)) or inferred from the key names (graph_finalization.py:1024-1058,
-        # :591-624, :698); no candidate = the structural config, the keys every input holds with one shape (:695-696)
+        # :591-624, :698); no candidate = the structural config (:695-696)
         config = model_configs.infer([readers[id(m)].keys() for m in merge_inputs], [getattr(m, "config", None) for m in merge_inputs])
         if config is not None:
             for m in merge_inputs:                                           # inputs may name a key by an alias (merging.py:394-403)
                 readers[id(m)].apply_aliases(config.resolve_alias)
-        first = readers[id(merge_inputs[0])]
+        # the keys the recipe can produce (graph_finalization.py:113-141, structural form: GraphInfo), in the config's order
+        # (merging.py:202) or the order the inputs hold them.  A key some input lacks is still produced when a `|` further
+        # up has a default for it (logistics.py:15-19).
+        info = GraphInfo(recipe, readers)
+        root_keys = info.keys(recipe)
+        if root_keys is None:
+            raise ValueError("the recipe has no model inputs")
+        if config is not None:
+            order = [k for k in config.keys() if k in root_keys]
+        else:                                                               # structural config = the keys every input holds (:626-637, :695-696)
+            common = set.intersection(*[set(readers[id(m)].keys()) for m in merge_inputs])
+            order = [k for k in root_keys if k in common]
         items, header = [], {}
-        for key in (config.keys() if config is not None else first.keys()):
-            if key not in first:
-                continue                                                     # StateDictKeyError -> the key is skipped (merging.py:312-316)
-            meta = first.meta(key)
-            ok = all(key in readers[id(m)] and readers[id(m)].meta(key).shape == meta.shape for m in merge_inputs)
-            if ok:
-                items.append((key, meta.numel()))
-                header[key] = TensorMetadata(meta.shape, output_dtype)
+        for key in order:
+            shape = root_keys[key]
+            items.append((key, int(math.prod(shape))))
+            header[key] = TensorMetadata(shape, output_dtype)
         log.debug("model config: %s, %d keys", config.identifier if config is not None else "structural", len(items))
         my_items = shard_keys_lpt(items, world)[rank] if world > 1 else items
         order = {k: i for i, (k, _) in enumerate(items)}
@@ -410,26 +490,38 @@ def merge(
             sizes = [sum(n for _, n in shard) * esz for shard in (shard_keys_lpt(items, world) if world > 1 else [items])]
             region_start = sum(sizes[:rank])
             if world > 1:
+                reserved = [False]
                 if rank == 0:
                     sink = OutSafetensorsDict(out_path, header, recipe_text, create=True, region_start=region_start)
-                dist.barrier()
+                    reserved[0] = sink.wait_reserved()          # the other ranks store into pages rank 0 allocated
+                dist.broadcast_object_list(reserved, src=0)     # control message; also the "file exists" barrier
                 if rank != 0:
-                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=False, region_start=region_start)
+                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=False, region_start=region_start,
+                                              pages_reserved=bool(reserved[0]))
             else:
                 sink = OutSafetensorsDict(out_path, header, recipe_text)
         else:
             sink = output if output is not None else {}
             sink["__metadata__"] = {"mecha_recipe": recipe_text}              # merging.py:287-288
 
+        # Keys the batched kernels cover go through the fused pipeline, one run per storage dtype the inputs hold them in
+        # (a checkpoint may keep, say, its VAE in fp32 beside a bf16 UNet); everything else -- integer keys (position_ids: the
+        # reference casts them to fp32 like any other key, merging.py:673-681), keys whose inputs disagree on the dtype, empty
+        # tensors, keys one of the fused inputs lacks -- is evaluated per key into the same sink.
         skipped: List[str] = []
-        if plan is not None and _fusable_dtypes(plan, readers, my_items):
-            _run_fused(plan, backend, readers, my_items, header, sink, to_file, output_device, output_dtype,
+        last_stats.clear()
+        groups, generic_items = _split_fusable(plan, readers, my_items, header)
+        for in_dtype, group_items in groups.items():
+            _run_fused(plan, backend, readers, group_items, in_dtype, header, sink, to_file, output_device, output_dtype,
                        total_buffer_size, check_finite_output, skipped)
-        else:
+        if generic_items:
             if threads is None:
                 threads = min(max(len(models), 2), os.cpu_count() or 1, 4)       # merging.py:171-172
-            _run_generic(recipe, backend, readers, my_items, header, sink, to_file, output_device, output_dtype,
-                         check_finite_output, strict_mandatory_keys, skipped, cache or {}, threads)
+            with _phase("generic"):
+                _run_generic(recipe, info, backend, readers, generic_items, header, sink, to_file, output_device, output_dtype,
+                             check_finite_output, strict_mandatory_keys, skipped, cache or {}, threads)
+        last_stats["fused_keys"] = sum(len(g) for g in groups.values())
+        last_stats["generic_keys"] = len(generic_items)
         for k in skipped:
             log.debug("Skipping key: %s", k)
 
@@ -461,15 +553,30 @@ def merge(
             r.close()
 
 
-def _fusable_dtypes(plan: FusedPlan, readers, items) -> bool:
-    """The batched kernels read one storage dtype for every input; mixed or integer checkpoints go generic."""
-    if not items:
-        return True
-    dts = set()
-    for key, _ in items:
-        for m in plan.models:
-            dts.add(readers[id(m)].meta(key).dtype)
-    return len(dts) == 1 and next(iter(dts)) in _DT_CODE
+def _split_fusable(plan: Optional[FusedPlan], readers, items, header):
+    """({storage dtype: [(key, numel)]}, [(key, numel) for the per-key path]).  A key is fused when the recipe is one the
+    batched kernels cover and every input of the plan holds it, non-empty, with the output's shape and ONE of the storage
+    dtypes the kernels read (fp32 / fp16 / bf16)."""
+    groups: Dict[torch.dtype, list] = {}
+    generic = []
+    for key, n in items:
+        dt = None
+        if plan is not None and n > 0:
+            for m in plan.models:
+                r = readers[id(m)]
+                if key not in r:
+                    dt = None
+                    break
+                meta = r.meta(key)
+                if meta.shape != header[key].shape or meta.dtype not in _DT_CODE or (dt is not None and meta.dtype != dt):
+                    dt = None
+                    break
+                dt = meta.dtype
+        if dt is None:
+            generic.append((key, n))
+        else:
+            groups.setdefault(dt, []).append((key, n))
+    return groups, generic
 
 
 class NullSink(dict):
@@ -479,11 +586,10 @@ class NullSink(dict):
 
 
 # ------------------------------------------------------------------ fused (batched) path
-def _run_fused(plan, backend, readers, items, header, sink, to_file, output_device, output_dtype, total_buffer_size,
+def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, output_device, output_dtype, total_buffer_size,
                check_finite_output, skipped):
     dev = backend.device
     is_cuda = dev.type == "cuda"
-    in_dtype = readers[id(plan.models[0])].meta(items[0][0]).dtype if items else torch.float16
     n_models = len(plan.models)
     in_esz, out_esz = DTYPE_REVERSE_MAPPING[in_dtype][1], DTYPE_REVERSE_MAPPING[output_dtype][1]
     # buffer sets (2 = double buffering), each holding n_models inputs + 1 output; the budget is shared between them
@@ -505,7 +611,6 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
             "d_out": torch.empty(cap, dtype=output_dtype, device=dev),
             "flags": None, "h_flags": None, "ev_h2d": None, "ev_comp": None, "ev_d2h": None, "wave": None,
         }
-    last_stats.clear()
     with _phase("alloc"):
         sets = [alloc_set() for _ in range(min(n_sets, len(waves)))]
     s_copy_in = backend.stream() if is_cuda else None
@@ -657,7 +762,7 @@ def _run_fused(plan, backend, readers, items, header, sink, to_file, output_devi
     writer.shutdown()
     if is_cuda:
         torch.cuda.synchronize(dev)
-    last_stats["waves"] = len(waves)
+    last_stats["waves"] = last_stats.get("waves", 0) + len(waves)
 
 
 def _write_fallback(plan, readers, key, meta, sink, to_file, output_device, output_dtype) -> bool:
@@ -688,45 +793,161 @@ class _null:
 
 
 # ------------------------------------------------------------------ generic (per key) path
-def _run_generic(recipe, backend, readers, items, header, sink, to_file, output_device, output_dtype, check_finite_output,
-                 strict_mandatory_keys, skipped, cache, threads=0):
-    """KeyMergeVisitor (merging.py:374-482) for graphs the fuser does not cover: every model value is uploaded,
-    cast to fp32 with the fused finite check, and the method bodies run per key on device tensors."""
-    dev = backend.device
-    methods = backend.methods
+class _LazyStateDict(Mapping):
+    """MergeNodeWrapperStateDict (merging.py:566-608): what a ``StateDict``-typed parameter receives.  Indexing it evaluates
+    the input node for that key -- a body that never indexes it never loads it."""
 
-    def evaluate(node: RecipeNode, key: str):
-        if isinstance(node, ModelRecipeNode):
-            reader = readers[id(node)]
+    def __init__(self, node: RecipeNode, run: "_KeyRun", interface):
+        self.node, self._run, self._interface = node, run, interface
+
+    def __getitem__(self, key):
+        return self._run.value(self.node, key, self._interface)
+
+    def keys(self):
+        ks = self._run.ex.info.keys(self.node)
+        return ks.keys() if ks is not None else ()
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def __contains__(self, key):
+        ks = self._run.ex.info.keys(self.node)
+        return ks is None or key in ks
+
+
+class _KeyRun:
+    """One key's evaluation: KeyMergeVisitor (merging.py:374-482).  `memo` holds the outputs of nodes with several consumers
+    for the keys requested so far (merge_context.py:164-205 keeps them until the last consumer has read them; here they
+    live until the key is done -- the same values, released together)."""
+
+    def __init__(self, ex: "_GenericExecutor"):
+        self.ex = ex
+        self.memo: Dict[Tuple[int, str], Any] = {}
+
+    def value(self, node: RecipeNode, key: str, interface=None):
+        return _cast_node_value(self.node_value(node, key), interface)
+
+    def node_value(self, node: RecipeNode, key: str):
+        ex = self.ex
+        shared = ex.memoize and ex.info.consumers.get(id(node), 0) > 1
+        if shared and (id(node), key) in self.memo:
+            hit = self.memo[(id(node), key)]
+            if isinstance(hit, _Raised):
+                raise hit.error
+            return hit
+        try:
+            res = self._compute(node, key)
+        except StateDictKeyError as e:
+            if shared:
+                self.memo[(id(node), key)] = _Raised(e)
+            raise
+        if shared:
+            self.memo[(id(node), key)] = res
+        return res
+
+    def _compute(self, node: RecipeNode, key: str):
+        ex = self.ex
+        if isinstance(node, ModelRecipeNode):                                  # visit_model (merging.py:391-403) + the cast and
+            reader = ex.readers[id(node)]                                      # omit_non_finite nodes above it (:673-681)
             if key not in reader:
                 raise StateDictKeyError(key)
-            t = reader[key].to(dev)
+            t = reader[key].to(ex.dev)
             if t.dtype in _DT_CODE and t.numel():
-                return methods.cast(t, torch.float32, key=key)                 # cast + omit_non_finite (merging.py:673-681)
+                return ex.methods.cast(t, torch.float32, key=key)
             return t.to(torch.float32)
         if isinstance(node, LiteralRecipeNode):
-            return node.value
-        if isinstance(node, MergeRecipeNode):
-            if node.merge_method.identifier == "fallback":
-                for cand in node.args:
-                    try:
-                        return evaluate(cand, key)
-                    except StateDictKeyError:
-                        continue
-                raise StateDictKeyError(key)
-            if node.merge_method.identifier == "convert_lora_to_base":        # LycorisToBase.__call__ (lycoris.py:69-85)
-                lora_node, base_node = node.args
-                reader, meta = readers[id(lora_node)], readers[id(base_node)].meta(key)
-                prefix = lora_mod.lora_key_prefix(key, tuple(meta.shape), meta.dtype.is_floating_point)
-                if prefix is None:
+            if isinstance(node.value, Mapping):
+                if key not in node.value:
                     raise StateDictKeyError(key)
-                up_k, down_k, alpha_k = lora_mod.network_entries(reader, prefix)
-                alpha = reader[alpha_k] if alpha_k is not None else None
-                return methods.lora_delta(reader[up_k].to(dev), reader[down_k].to(dev), alpha, tuple(meta.shape))
-            args = [evaluate(a, key) for a in node.args]
-            kwargs = {k: evaluate(v, key) for k, v in node.kwargs.items()}
-            return node.merge_method.merge_key(args, kwargs, key, cache.get(node))
-        raise TypeError(type(node))
+                v = node.value[key]
+                if isinstance(v, torch.Tensor):
+                    v = v.to(ex.dev)
+                    if v.dtype in _DT_CODE and v.numel():
+                        return ex.methods.cast(v, torch.float32, key=key)
+                    return v.to(torch.float32)
+                return v
+            return node.value
+        if not isinstance(node, MergeRecipeNode):
+            raise TypeError(type(node))
+        method = node.merge_method
+        node_keys = ex.info.keys(node)
+        if node_keys is not None and key not in node_keys:                     # merging.py:412-414
+            raise StateDictKeyError(key)
+        if method.identifier == "convert_lora_to_base":                        # LycorisToBase.__call__ (lycoris.py:69-85)
+            lora_node, base_node = node.args
+            reader, meta = ex.readers[id(lora_node)], ex.readers[id(base_node)].meta(key)
+            prefix = lora_mod.lora_key_prefix(key, tuple(meta.shape), meta.dtype.is_floating_point)
+            if prefix is None:
+                raise StateDictKeyError(key)
+            up_k, down_k, alpha_k = lora_mod.network_entries(reader, prefix)
+            alpha = reader[alpha_k] if alpha_k is not None else None
+            return ex.methods.lora_delta(reader[up_k].to(ex.dev), reader[down_k].to(ex.dev), alpha, tuple(meta.shape))
+        # __visit_deeper_first (merging.py:446-482): StateDict-typed parameters become lazy mappings; the others are
+        # evaluated now, deepest input first, every one of them even after an error (ErrorHolder :544-563)
+        names = method.param_names(len(node.args))
+        slots = [(i, names[i], a) for i, a in enumerate(node.args)] + [(k, k, a) for k, a in node.kwargs.items()]
+        merged: Dict[Any, Any] = {}
+        error = None
+        for index, pname, child in sorted(slots, key=lambda s: ex.info.depth.get(id(s[2]), 0), reverse=True):
+            iface = method.param_interfaces.get(pname)
+            if pname in method.lazy_params:
+                merged[index] = _LazyStateDict(child, self, getattr(iface, "item", None))
+            else:
+                try:
+                    merged[index] = self.value(child, key, iface)
+                except Exception as e:                                          # noqa: BLE001 -- re-raised below
+                    error, merged[index] = e, None
+        if error is not None:
+            raise error
+        args = [merged[i] for i in range(len(node.args))]
+        kwargs = {k: v for k, v in merged.items() if not isinstance(k, int)}
+        meta = None
+        if method.identifier == "fallback":                                    # logistics.py:15-19: the inputs that can produce the key
+            def can_produce(child):
+                ks = ex.info.keys(child)
+                return ks is None or key in ks
+            meta = tuple(pname for _, pname, child in slots if can_produce(child))
+        relation = RealizedKeyRelation((key,), {pname: (key,) for _, pname, _ in slots}, meta)
+        return method.merge_key(args, kwargs, key, relation, ex.cache.get(node), ex.info.instances.get(id(node)), ex.memoize,
+                                body=ex.bodies.get(method.identifier))
+
+
+class _Raised:
+    def __init__(self, error):
+        self.error = error
+
+
+def _cast_node_value(value, interface):
+    """cast_node_value (merging.py:611-636): python values bound to a ``Tensor`` parameter become 0-d fp32 CPU tensors."""
+    if value is None or interface is None or isinstance(interface, str):
+        return value
+    if interface is torch.Tensor:
+        return value if isinstance(value, torch.Tensor) else torch.tensor(value, dtype=torch.float32)
+    if isinstance(interface, type) and not isinstance(value, interface):
+        if interface in (int, float, bool):
+            return interface(value)
+    return value
+
+
+class _GenericExecutor:
+    def __init__(self, info: GraphInfo, backend, readers, cache, memoize=True):
+        self.info, self.readers, self.cache, self.memoize = info, readers, cache, memoize
+        self.dev, self.methods = backend.device, backend.methods
+        self.bodies = getattr(backend, "bodies", None) or {}           # {identifier: body}: a backend's own method bodies
+
+
+def _run_generic(recipe, info, backend, readers, items, header, sink, to_file, output_device, output_dtype, check_finite_output,
+                 strict_mandatory_keys, skipped, cache, threads=0):
+    """KeyMergeVisitor (merging.py:374-482) for keys and graphs the fuser does not cover: every model value is uploaded,
+    cast to fp32 with the fused finite check, and the method bodies run per key on device tensors."""
+    dev = backend.device
+    ex = _GenericExecutor(info, backend, readers, cache)
+
+    def evaluate(node: RecipeNode, key: str):
+        return _KeyRun(ex).node_value(node, key)
 
     lock = threading.Lock()
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import inspect
 import pathlib
-from typing import Any, Callable, Dict, List, Optional, Tuple
+from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Tuple
 
 
 class RecipeNode:
@@ -84,17 +84,101 @@ def literal(value) -> LiteralRecipeNode:
     return LiteralRecipeNode(value)
 
 
+# ------------------------------------------------------------------ parameter annotations (merge_methods.py:41-144)
+class StateDict(Mapping):
+    """``StateDict[T]`` (merge_methods.py:25-38): the annotation of a parameter the executor hands over LAZILY -- a mapping
+    that evaluates its recipe node for a key when the body indexes it (merging.py:566-608), so a body that returns
+    ``a[key]`` never loads ``b``."""
+
+    def __class_getitem__(cls, item):
+        return _StateDictAlias(item)
+
+
+class _StateDictAlias:
+    def __init__(self, item):
+        self.item = item
+
+    def __repr__(self):
+        return f"StateDict[{getattr(self.item, '__name__', self.item)}]"
+
+
+class ParameterType:
+    interface: Any = None
+    merge_space: Any = None
+    model_config: Any = None
+
+
+class ReturnType(ParameterType):
+    pass
+
+
+def Parameter(interface, merge_space=None, model_config=None):
+    """``Parameter(interface, merge_space, model_config)`` (merge_methods.py:53-101).  Only ``interface`` changes what the
+    executor passes: ``StateDict[...]`` = lazy mapping, ``Tensor`` = tensor (python scalars become 0-d fp32 CPU tensors,
+    merging.py:632-633), ``float`` / ``int`` / ``bool`` / ``str`` = python values (merging.py:626-631).  Merge spaces and
+    configs belong to the graph layer (out of scope) and are kept only as attributes."""
+    return type("Parameter", (ParameterType,), {"interface": interface, "merge_space": merge_space, "model_config": model_config})
+
+
+def Return(interface, merge_space=None, model_config=None):
+    """merge_methods.py:109-144."""
+    return type("Return", (ReturnType,), {"interface": interface, "merge_space": merge_space, "model_config": model_config})
+
+
+class RealizedKeyRelation:
+    """keys_map.py:18-26: ``outputs`` (the keys one call produces), ``inputs`` (per parameter, the keys it may read),
+    ``meta``.  Iterates as (outputs, inputs) like the reference, so ``(key,), _ = kwargs["key_relation"]`` works."""
+    __slots__ = ("outputs", "inputs", "meta")
+
+    def __init__(self, outputs, inputs, meta=None):
+        self.outputs, self.inputs, self.meta = tuple(outputs), inputs, meta
+
+    def __iter__(self):
+        yield self.outputs
+        yield self.inputs
+
+    def __repr__(self):
+        return f"RealizedKeyRelation(outputs={self.outputs}, inputs={dict(self.inputs)}, meta={self.meta})"
+
+
+def _interface_of(annotation):
+    if isinstance(annotation, type) and issubclass(annotation, ParameterType):
+        return annotation.interface
+    return annotation
+
+
 class MergeMethod:
     """merge_methods.py:182-445, reduced to what the hot path needs: an identifier, the raw body
-    (``__wrapped__``), and ``__call__`` that builds a recipe node when given nodes and runs the body when
-    given tensors."""
+    (``__wrapped__``: a function, or a class with ``__call__`` that is instantiated once per recipe node,
+    merge_context.py:94), ``__call__`` that builds a recipe node when given nodes and runs the body when given tensors,
+    and ``merge_key``."""
 
-    def __init__(self, fn: Callable, identifier: Optional[str] = None, cache_factory: Optional[Callable] = None):
+    def __init__(self, fn: Callable, identifier: Optional[str] = None, cache_factory: Optional[Callable] = None,
+                 lazy: Sequence[str] = (), reuse_outputs: bool = True):
         self.__wrapped__ = fn
+        self.wrapped_is_class = inspect.isclass(fn)
         self.cache_factory = cache_factory
+        self.reuse_outputs = reuse_outputs
         self.identifier = identifier or fn.__name__
-        self.signature = inspect.signature(fn)
-        self.accepts_kwargs = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in self.signature.parameters.values())
+        sig = inspect.signature(fn.__call__ if self.wrapped_is_class else fn)
+        if self.wrapped_is_class and not isinstance(inspect.getattr_static(fn, "__call__"), (classmethod, staticmethod)):
+            sig = sig.replace(parameters=list(sig.parameters.values())[1:])          # drop self (merge_methods.py:214-217)
+        self.signature = sig
+        self.accepts_kwargs = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())
+        for reserved in ("key", "key_relation", "cache", "output_reused"):             # merge_methods.py:262-264
+            p = sig.parameters.get(reserved)
+            if p is not None and p.annotation is not p.empty and _interface_of(p.annotation) is not p.annotation:
+                raise TypeError(f"A merge method cannot define a parameter named {reserved}.")
+        # how each parameter is handed over (merging.py:469-477)
+        self.param_interfaces: Dict[str, Any] = {}
+        self.lazy_params = set(lazy)
+        for p in sig.parameters.values():
+            if p.kind == p.VAR_KEYWORD:
+                continue
+            iface = _interface_of(p.annotation) if p.annotation is not p.empty else None
+            self.param_interfaces[p.name] = iface
+            if isinstance(iface, _StateDictAlias) or iface is StateDict:
+                self.lazy_params.add(p.name)
         self.__name__ = self.identifier
         self.__doc__ = fn.__doc__
 
@@ -104,31 +188,65 @@ class MergeMethod:
     def __call__(self, *args, **kwargs):
         if any(isinstance(a, RecipeNode) for a in args) or any(isinstance(a, RecipeNode) for a in kwargs.values()):
             return MergeRecipeNode(self, tuple(value_to_node(a) for a in args), {k: value_to_node(v) for k, v in kwargs.items()})
+        if self.wrapped_is_class:
+            return self.__wrapped__()(*args, **kwargs)
         return self.__wrapped__(*args, **kwargs)
 
     def create_cache(self):
         """merge_methods.py:271: a fresh cache object for one node of this method, or None if the method keeps none."""
         return self.cache_factory() if self.cache_factory is not None else None
 
-    def merge_key(self, args, kwargs, key: str, cache=None):
-        """merge_methods.py:304-337: extra kwargs only if the body declares **kwargs or names them."""
-        extra = {}
-        if self.accepts_kwargs or "key" in self.signature.parameters:
-            extra["key"] = key
-        if self.accepts_kwargs or "cache" in self.signature.parameters:
-            extra["cache"] = cache
-        return self.__wrapped__(*args, **kwargs, **extra)
+    def instantiate(self):
+        """merge_methods.py:266-269."""
+        return self.__wrapped__() if self.wrapped_is_class else None
+
+    def param_names(self, n_args: int) -> List[str]:
+        """Parameter name of each positional argument (a ``*varargs`` parameter repeats)."""
+        names, var = [], None
+        for p in self.signature.parameters.values():
+            if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD):
+                names.append(p.name)
+            elif p.kind == p.VAR_POSITIONAL:
+                var = p.name
+        if len(names) < n_args:
+            if var is None:
+                raise TypeError(f"{self.identifier}: takes {len(names)} positional arguments but {n_args} were given")
+            names += [var] * (n_args - len(names))
+        return names[:n_args]
+
+    def merge_key(self, args, kwargs, key: str, key_relation=None, cache=None, context=None, output_reused: bool = True,
+                  body: Optional[Callable] = None):
+        """merge_methods.py:304-337: the body is called as fn(*args, **kwargs); a body that declares ``**kwargs`` also
+        receives ``key``, ``key_relation``, ``cache`` and ``output_reused``.  (Extension kept from round 1: a body without
+        ``**kwargs`` that NAMES ``key`` or ``cache`` as a keyword parameter receives that one.)"""
+        kwargs = dict(kwargs)
+        if self.accepts_kwargs:
+            kwargs.update(key=key, key_relation=key_relation, cache=cache, output_reused=output_reused)
+        else:
+            if "key" in self.signature.parameters:
+                kwargs["key"] = key
+            if "cache" in self.signature.parameters:
+                kwargs["cache"] = cache
+        if body is not None:                         # a backend's own body for this identifier (tests: the CPU double)
+            return body(*args, **kwargs)
+        if self.wrapped_is_class:
+            if context is None:
+                raise AssertionError(f"class merge method {self.identifier} received self=None")
+            return context(*args, **kwargs)
+        return self.__wrapped__(*args, **kwargs)
 
 
 _registry: Dict[str, MergeMethod] = {}
 
 
 def merge_method(fn: Optional[Callable] = None, *, identifier: Optional[str] = None, register: bool = True,
-                 cache_factory: Optional[Callable] = None):
-    """``@merge_method`` (merge_methods.py:665-711): wrap a per-key function and register it by identifier.
-    ``cache_factory`` as in the reference (svd.py:10: ``lambda: defaultdict(dict)``)."""
+                 cache_factory: Optional[Callable] = None, lazy: Sequence[str] = (), reuse_outputs: bool = True):
+    """``@merge_method`` (merge_methods.py:665-711): wrap a per-key function (or a class with ``__call__``) and register it
+    by identifier.  ``cache_factory`` as in the reference (svd.py:10: ``lambda: defaultdict(dict)``).  ``lazy``: names of
+    parameters to hand over as lazy ``StateDict`` mappings when the body carries no ``Parameter(StateDict[...])``
+    annotations (this package's own shims)."""
     def wrap(f):
-        mm = MergeMethod(f, identifier, cache_factory)
+        mm = MergeMethod(f, identifier, cache_factory, lazy, reuse_outputs)
         if register:
             if mm.identifier in _registry:
                 raise ValueError(f"merge method {mm.identifier!r} is already registered")

@@ -193,7 +193,7 @@ class OutSafetensorsDict:
     the sub-headers (``close(extra_entries=...)``)."""
 
     def __init__(self, file_path, header: Mapping[str, TensorMetadata], mecha_recipe: Optional[str], *,
-                 create: bool = True, region_start: int = 0):
+                 create: bool = True, region_start: int = 0, pages_reserved: bool = False):
         self.file_path = pathlib.Path(file_path)
         self.metadata = {"mecha_recipe": mecha_recipe} if mecha_recipe is not None else {}
         self.max_header_size = _worst_case_header_size(header, self.metadata)
@@ -201,6 +201,8 @@ class OutSafetensorsDict:
         flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
         self._fd = os.open(self.file_path, flags, 0o644)
         self._prealloc = None
+        self._pages_reserved = pages_reserved and not create     # create=False: the creating rank says whether it reserved the pages
+        self._prealloc_error: Optional[OSError] = None
         if create:
             # Full length up front (every key of the header merged): put_many stores through a mapping of the file.
             # Allocating the pages first (in the background, while the first wave is staged) makes those stores 3x
@@ -211,8 +213,12 @@ class OutSafetensorsDict:
             def prealloc(fd=self._fd):
                 try:
                     os.posix_fallocate(fd, 0, size)
-                except OSError:
-                    pass                                   # file systems without fallocate: the ftruncate above is enough
+                    self._pages_reserved = True
+                except OSError as e:
+                    # no fallocate here, or not enough room (ENOSPC on a size-limited tmpfs): the file stays sparse, and a
+                    # store through a mapping of a page the file system cannot back kills the process with SIGBUS.  put_many
+                    # then writes with pwrite, which reports the error instead.
+                    self._prealloc_error = e
             self._prealloc = threading.Thread(target=prealloc, daemon=True)
             self._prealloc.start()
         self._lock = threading.Lock()
@@ -247,7 +253,9 @@ class OutSafetensorsDict:
         srcs = np.ascontiguousarray(src_ptrs, dtype=np.uint64)
         offs = np.ascontiguousarray(rel + self.data_start, dtype=np.int64)
         args = (self._fd, srcs.ctypes.data, sizes.ctypes.data, offs.ctypes.data, len(keys), threads)
-        if _lib.lib().mecha_host_mmap_write_many(*args) != 0:               # e.g. a file system without shared mappings
+        # stores through a shared mapping only where the pages are known to exist; otherwise (and when the mapping itself
+        # fails, e.g. a file system without shared mappings) positional writes, whose ENOSPC / EIO come back as errors
+        if not self._pages_reserved or _lib.lib().mecha_host_mmap_write_many(*args) != 0:
             _lib.check(_lib.lib().mecha_host_pwrite_many(*args), "mecha_host_pwrite_many")
         for key, meta, off, n in zip(keys, metas, rel.tolist(), sizes.tolist()):
             self.entries[key] = {"dtype": DTYPE_REVERSE_MAPPING[meta.dtype][0], "shape": list(meta.shape), "data_offsets": [off, off + n]}
@@ -259,6 +267,11 @@ class OutSafetensorsDict:
     @property
     def bytes_written(self) -> int:
         return self._cursor
+
+    def wait_reserved(self) -> bool:
+        """Wait for the background page reservation; False when the file stayed sparse."""
+        self._join_prealloc()
+        return self._pages_reserved
 
     def _join_prealloc(self):
         t, self._prealloc = self._prealloc, None

@@ -142,14 +142,17 @@ def gen_dare(out):
     for shape in [(16,), (33, 7), (48, 32)]:
         for n_models in (2, 3):
             deltas = [torch.from_numpy(rng.normal(0, 0.02, size=shape).astype(np.float32)) for _ in range(n_models)]
-            for seed in (0, 114514):
+            for seed in (0, 114514, -1):                 # -1 stands for seed=None: the generator is never seeded (ties.py:29-31)
                 for p in (0.4, 0.9):
+                    if seed < 0 and (p != 0.4 or n_models != 2):
+                        continue
                     pre = f"d{case}"
                     out[pre + "_deltas"] = np.stack([bits(d) for d in deltas])
                     out[pre + "_seed"] = np.array(seed)
                     out[pre + "_p"] = np.array(p)
                     g = torch.Generator("cpu")
-                    g.manual_seed(seed)
+                    if seed >= 0:
+                        g.manual_seed(seed)
                     masks = [ties.find_della_dropout(d, torch.tensor(p), 0.0, g) for d in deltas]
                     out[pre + "_masks"] = np.packbits(np.stack([m.numpy().astype(bool).reshape(-1) for m in masks]), axis=1)
                     for apply_stock in (True, False):
@@ -157,7 +160,7 @@ def gen_dare(out):
                             res = ties.ties_sum_with_dropout.__wrapped__(
                                 *deltas, probability=torch.tensor(p), della_eps=0.0, rescale=rescale, k=0.5,
                                 vote_sgn=False, apply_stock=apply_stock, cos_eps=1e-6, apply_median=False,
-                                eps=1e-6, maxiter=100, ftol=1e-20, seed=seed)
+                                eps=1e-6, maxiter=100, ftol=1e-20, seed=seed if seed >= 0 else None)
                             out[f"{pre}_stock{int(apply_stock)}_rescale{int(rescale)}"] = bits(res)
                     case += 1
     out["n_cases"] = np.array(case)
@@ -266,6 +269,100 @@ def gen_e2e(out):
     out["shapes_keys"] = np.array(list(shapes.keys()))
 
 
+def gen_e2e_mixed(out):
+    """Executor semantics through the real sd_mecha.merge on checkpoints shaped like real ones: an int64
+    position_ids key, an fp32 key and an EMPTY int64 key among bf16 keys (the reference casts every key to fp32 and the result
+    to the output dtype, merging.py:157-158, :673-681); a lazily skipped non-finite input (merging.py:579-589); a node with two
+    consumers (merge_context.py:164-205); a user method that reads the four extra kwargs (merge_methods.py:330-337); and a
+    `|` default that holds keys its left side lacks, under a known config (logistics.py:15-19)."""
+    import safetensors.torch
+    from tqdm import tqdm
+    from sd_mecha.extensions.merge_methods import merge_method, Parameter, Return
+    from torch import Tensor
+
+    class quiet(tqdm):
+        def __init__(self, *a, **k):
+            k["disable"] = True
+            super().__init__(*a, **k)
+
+    seen = {}
+
+    @merge_method(identifier="golden_kwargs_sum")
+    def golden_kwargs_sum(a: Parameter(Tensor), b: Parameter(Tensor), alpha: Parameter(Tensor) = 0.5, **kwargs) -> Return(Tensor):
+        (key,), inputs = relation = kwargs["key_relation"]
+        assert key == kwargs["key"] and set(inputs) == {"a", "b", "alpha"} and inputs["a"] == (key,)
+        assert kwargs["cache"] is None and isinstance(kwargs["output_reused"], bool)
+        seen[key] = (kwargs["output_reused"], relation.meta, tuple(alpha.shape), str(alpha.device), alpha.dtype)
+        return (1 - alpha) * a + alpha * b
+
+    rng = np.random.default_rng(77)
+    shapes = {"w.linear": (96, 64), "w.conv": (16, 8, 3, 3), "w.bias": (96,)}
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        paths = []
+        for m in range(3):
+            state = {k: rand_half(rng, s, "bfloat16") for k, s in shapes.items()}
+            state["w.f32"] = torch.from_numpy(rng.normal(0, 0.02, size=(40, 24)).astype(np.float32))
+            state["w.position_ids"] = torch.arange(77, dtype=torch.int64).reshape(1, 77) + m
+            state["w.empty"] = torch.zeros((0,), dtype=torch.int64)
+            if m == 1:
+                state["w.bias"][3] = float("nan")
+            p = td / f"m{m}.safetensors"
+            safetensors.torch.save_file(state, str(p))
+            paths.append(p)
+            for k, t in state.items():
+                out[f"x_m{m}_{k}"] = bits(t) if t.is_floating_point() else t.numpy()
+        out["x_keys"] = np.array(list(state.keys()))
+        models = [sd_mecha.model(p) for p in paths]
+        kw = dict(threads=0, output_dtype=torch.bfloat16, tqdm=quiet)
+
+        def store(name, res):
+            res = {k: v for k, v in res.items() if k != "__metadata__"}
+            out[f"x_{name}_keys"] = np.array(sorted(res.keys()))
+            for k, v in res.items():
+                assert v.dtype == torch.bfloat16, (name, k, v.dtype)
+                out[f"x_{name}_{k}"] = bits(v)
+                out[f"x_{name}_{k}_shape"] = np.array(v.shape, dtype=np.int64)
+
+        store("wsum", sd_mecha.merge(linear.weighted_sum(models[0], models[2], alpha=0.3), **kw))
+        store("wsum_nan_b", sd_mecha.merge(linear.weighted_sum(models[0], models[1], alpha=0.3), **kw))     # w.bias skipped
+        store("wsum_lazy0", sd_mecha.merge(linear.weighted_sum(models[0], models[1], alpha=0.0), **kw))     # b never loaded: w.bias kept
+        store("wsum_lazy1", sd_mecha.merge(linear.weighted_sum(models[1], models[0], alpha=1.0), **kw))     # a never loaded
+        deltas = [linear.subtract(m, models[0]) for m in models[1:]]
+        store("ties_fb", sd_mecha.merge(linear.add_difference(models[0], ties.ties_sum(*deltas, k=0.5), alpha=1.0) | models[0], **kw))
+        d = linear.subtract(models[2], models[0])                              # one delta, two consumers
+        store("shared", sd_mecha.merge(linear.add_difference(linear.add_difference(models[0], d, alpha=0.5), d, alpha=0.25), **kw))
+        store("kwargs", sd_mecha.merge(golden_kwargs_sum(models[0], models[2], alpha=0.25), **kw))
+        out["x_kwargs_seen"] = np.array(json_dumps({k: [v[0], v[1], list(v[2]), v[3], str(v[4])] for k, v in seen.items()}))
+
+        # a `|` default with more keys than its left side, under a known config
+        kshapes = {"unet.out.2.weight": (4, 320, 3, 3), "unet.out.2.bias": (4,), "unet.input_blocks.0.0.bias": (320,),
+                   "te1.text_model.embeddings.position_embedding.weight": (77, 768)}
+        full = {k: rand_half(rng, s, "bfloat16") for k, s in kshapes.items()}
+        part_a = {k: rand_half(rng, kshapes[k], "bfloat16") for k in list(kshapes)[:2]}
+        part_b = {k: rand_half(rng, kshapes[k], "bfloat16") for k in list(kshapes)[:3]}
+        for name, sdict in (("full", full), ("part_a", part_a), ("part_b", part_b)):
+            safetensors.torch.save_file(sdict, str(td / f"{name}.safetensors"))
+            out[f"u_{name}_keys"] = np.array(list(sdict.keys()))
+            for k, t in sdict.items():
+                out[f"u_{name}_{k}"] = bits(t)
+        out["u_shapes"] = np.array(json_dumps({k: list(v) for k, v in kshapes.items()}))
+        fm, pa, pb = (sd_mecha.model(td / f"{n}.safetensors", config="sdxl-kohya") for n in ("full", "part_a", "part_b"))
+        res = {k: v for k, v in sd_mecha.merge(linear.weighted_sum(pa, pb, alpha=0.5) | fm, **kw).items() if k != "__metadata__"}
+        out["u_union_keys"] = np.array(sorted(res.keys()))
+        for k, v in res.items():
+            out[f"u_union_{k}"] = bits(v)
+        res = {k: v for k, v in sd_mecha.merge(linear.weighted_sum(pa, pb, alpha=0.5), fallback_model=fm, **kw).items() if k != "__metadata__"}
+        out["u_fallback_model_keys"] = np.array(sorted(res.keys()))
+        for k, v in res.items():
+            out[f"u_fallback_model_{k}"] = bits(v)
+
+
+def json_dumps(x):
+    import json
+    return json.dumps(x)
+
+
 def gen_e2e_lora(out):
     """sd_mecha.convert(model(lora_file), base) + add_difference through sd_mecha.merge (lycoris.py:52-85) on a
     toy checkpoint with REAL sdxl-kohya key names and shapes (LycorisToBase takes the target shape from the config).
@@ -371,7 +468,7 @@ def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
     only = set(sys.argv[1:])
     for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare),
-                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_lora", gen_e2e_lora),
+                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_mixed", gen_e2e_mixed), ("e2e_lora", gen_e2e_lora),
                      ("configs", gen_configs)]:
         if only and name not in only:
             continue

@@ -15,10 +15,89 @@ def _bits(t: torch.Tensor) -> np.ndarray:
     return t.view(torch.int16).numpy().view(np.uint16)
 
 
+class NonFinite(Exception):
+    pass
+
+
+def _np(t) -> np.ndarray:
+    return t.detach().cpu().float().contiguous().numpy()
+
+
+def _scalar(x) -> float:
+    return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
+
+
+class OracleMethods:
+    """What merging._KeyRun needs from `backend.methods` (cast of a loaded value, LoRA delta), by the oracle."""
+
+    @staticmethod
+    def cast(t, dtype=torch.float32, *, key=None, **_):
+        from sd_mecha_amd import NonFiniteStateDictKeyError
+        x = O.to_f32(_bits(t.contiguous().reshape(-1)), _NAME[t.dtype]) if t.dtype != torch.float32 else t.reshape(-1).numpy()
+        if not O.all_finite(x):
+            raise NonFiniteStateDictKeyError(key)
+        return torch.from_numpy(np.array(x, dtype=np.float32)).reshape(t.shape)
+
+    @staticmethod
+    def lora_delta(up, down, alpha=None, target_shape=None, **_):
+        a = None if alpha is None else float(torch.as_tensor(alpha).float())
+        up32, down32 = _np(up).reshape(up.shape[0], -1), _np(down).reshape(down.shape[0], -1)
+        return torch.from_numpy(O.lora_delta(up32, down32, a)).reshape(target_shape)
+
+
+def _resolve(x, key):
+    return x[key] if not isinstance(x, torch.Tensor) else x
+
+
+def _t(a: np.ndarray, like: torch.Tensor) -> torch.Tensor:
+    return torch.from_numpy(np.asarray(a, dtype=np.float32).copy()).reshape(like.shape)
+
+
+def _bodies():
+    """Method bodies by the oracle, on fp32 CPU tensors, for the identifiers the CPU tests of the per-key path use.  They
+    index their StateDict-typed parameters the way the reference's bodies do (linear.py:16-23, :35-39, :72-76)."""
+    import math
+
+    def weighted_sum(a, b, alpha=0.5, *, key=None, **_):
+        al = _scalar(alpha)
+        if math.isclose(al, 0.0):
+            return _resolve(a, key)
+        if math.isclose(al, 1.0):
+            return _resolve(b, key)
+        a, b = _resolve(a, key), _resolve(b, key)
+        return _t(O.weighted_sum(_np(a).reshape(-1), _np(b).reshape(-1), al), a)
+
+    def n_average(*models, key=None, **_):
+        ms = [_resolve(m, key) for m in models]
+        return _t(O.n_average([_np(m).reshape(-1) for m in ms]), ms[0])
+
+    def add_difference(a, b, alpha=1.0, *, key=None, **_):
+        al = _scalar(alpha)
+        if math.isclose(al, 0.0):
+            return _resolve(a, key)
+        b = _resolve(b, key)
+        a = _resolve(a, key)
+        return _t(O.add_difference(_np(a).reshape(-1), _np(b).reshape(-1), al), a)
+
+    def subtract(a, b, **_):
+        return _t(O.subtract(_np(a).reshape(-1), _np(b).reshape(-1)), a)
+
+    def ties_sum(*models, k=1.0, vote_sgn=False, **_):
+        if not models:
+            return 0
+        if models[0].numel() == 0:
+            return models[0]
+        return _t(O.ties_sum([_np(m).reshape(-1) for m in models], k=float(k), vote_sgn=bool(vote_sgn)), models[0])
+
+    return {"weighted_sum": weighted_sum, "n_average": n_average, "add_difference": add_difference, "subtract": subtract,
+            "ties_sum": ties_sum}
+
+
 class OracleBackend:
     def __init__(self):
         self.device = torch.device("cpu")
-        self.methods = None
+        self.methods = OracleMethods
+        self.bodies = _bodies()
         O.build()
 
     def stream(self):
@@ -34,7 +113,12 @@ class OracleBackend:
         fl = flags.numpy()
         for i, (off, n) in enumerate(zip(layout.offsets, layout.numels)):
             f32 = [O.to_f32(b[off:off + n], in_name) for b in a_bits]
-            if not all(O.all_finite(x) for x in f32):
+            used = f32
+            if plan.kind == "wsum" and O.isclose(plan.params["alpha"], 0.0):        # the kernel reads only `a` (linear.py:18-19)
+                used = f32[:1]
+            elif plan.kind == "wsum" and O.isclose(plan.params["alpha"], 1.0):
+                used = f32[1:2]
+            if not all(O.all_finite(x) for x in used):
                 fl[i] |= 1
                 continue
             if plan.kind == "wsum":
