@@ -8,8 +8,16 @@ read back.  `value` = (input tensor bytes + output tensor bytes actually merged)
 stripe of the job (weak scaling, no collective on the data path); the only distributed calls are the
 barrier around the timed region and the max-over-ranks of the elapsed time.
 
+After the timed loop the same workload also runs END TO END through `merge()` -- synthetic checkpoints written as
+.safetensors files on tmpfs (shaped as SURVEY.md §8d says: integer config keys as int64 arange, empty keys present) ->
+pread into pinned staging -> H2D -> kernels -> D2H -> one output file -- and the line carries `e2e`: wall seconds of merge()
+from the first read to close(), merged GB/s, H2D / D2H GB/s and the fraction of the measured pinned hipMemcpyAsync rate the
+slower direction of the host link was kept busy (`host_link_frac`).  With N ranks the ONE job is sharded over the ranks (keys
+dealt LPT, every rank fills its region of the one file): the e2e leg is strong scaling, the HBM-resident `value` weak.
+
     python bench.py                                   # N=1, SDXL add_difference+ties_sum of 4 bf16 checkpoints (BASELINE config 2)
     python bench.py --workload flux_navg              # one 1/8 shard of FLUX n_average of 8 checkpoints (config 3, per-GPU share)
+    python bench.py --gpus N                          # starts its own N ranks (torch.distributed.run) before any GPU call
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 """
 import argparse
@@ -17,6 +25,9 @@ import ctypes
 import json
 import os
 import pathlib
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -57,6 +68,12 @@ def parse_args():
     ap.add_argument("--workload", default="sdxl_ties", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU baseline sample")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end merge() leg (files on tmpfs -> file)")
+    ap.add_argument("--e2e-dir", default="/dev/shm", help="where the e2e leg keeps its synthetic checkpoints (tmpfs)")
+    ap.add_argument("--e2e-buffer-gib", type=float, default=8.0, help="merge(total_buffer_size=...) of the e2e leg, per rank")
+    ap.add_argument("--e2e-reps", type=int, default=2)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher rehearsal: ranks rendezvous over gloo and report, no GPU work (CPU test of --gpus N)")
     return ap.parse_args()
 
 
@@ -65,9 +82,12 @@ class Job:
 
     def __init__(self, workload: str, rank: int, device):
         manifest, comps, n_models, recipe, shards = WORKLOADS[workload]
-        items = [(k, numel(s)) for k, s, _ in load_manifest(manifest, comps)]
+        self.manifest = load_manifest(manifest, comps)
+        items = [(k, numel(s)) for k, s, _ in self.manifest]
         if shards > 1:
             items = shard_keys_lpt(items, shards)[rank % shards]
+            mine = {k for k, _ in items}
+            self.manifest = [e for e in self.manifest if e[0] in mine]
         self.recipe, self.n_models, self.device = recipe, n_models, device
         self.layout = plan_arena(items)
         L = self.layout
@@ -146,11 +166,162 @@ def cpu_baseline(job: Job, seconds: float):
                       f"of the same workload in {t_total:.1f} s; oracle/ C restatement with {threads} OpenMP threads"}
 
 
+# ------------------------------------------------------------------ end to end: files -> merge() -> file
+def link_rate(device, nbytes=1 << 30, reps=4):
+    """Pinned-memory hipMemcpyAsync rate of this GPU's host link, each direction on its own (the host-link roofline)."""
+    h = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    out = {}
+    for name, (dst, src) in {"h2d": (d, h), "d2h": (h, d)}.items():
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 2)
+    return out
+
+
+def write_checkpoints(job: Job, work: pathlib.Path):
+    """The job's synthetic checkpoints as .safetensors files: float keys in bf16 from the arenas already in
+    HBM (one D2H of each arena into pinned memory, one scatter list per file), integer config keys (position_ids) as int64
+    arange, empty keys present."""
+    from sd_mecha_amd.streaming import OutSafetensorsDict, TensorMetadata
+    L = job.layout
+    at = {k: (o, n) for k, o, n in zip(L.keys, L.offsets, L.numels)}
+    pinned = torch.empty(L.total_elems, dtype=torch.bfloat16, pin_memory=True)
+    paths = []
+    for m, arena in enumerate(job.arenas):
+        header, float_keys, int_tensors = {}, [], {}
+        for key, shape, dtype in job.manifest:
+            if dtype.startswith("int"):
+                n = numel(shape)
+                int_tensors[key] = torch.arange(n, dtype=torch.int64).reshape(shape)
+                header[key] = TensorMetadata(shape, torch.int64)
+            else:
+                header[key] = TensorMetadata(shape, torch.bfloat16)
+                float_keys.append(key)
+        p = work / f"m{m}.safetensors"
+        sink = OutSafetensorsDict(p, header, None)
+        pinned.copy_(arena, non_blocking=False)
+        base = pinned.data_ptr()
+        sink.put_many(float_keys, [header[k] for k in float_keys], [base + at[k][0] * 2 for k in float_keys], 16)
+        for key, t in int_tensors.items():
+            sink[key] = t
+        sink.close()
+        paths.append(p)
+    return paths
+
+
+def e2e_leg(job: Job, args, rank: int, world: int, dist, device):
+    """merge() of the whole workload, first read to close(), on files the driver can see nothing of but their size."""
+    import sd_mecha_amd as amd
+    work = pathlib.Path(args.e2e_dir) / f"mecha_bench_{os.environ.get('MASTER_PORT', os.getpid())}"
+    need = job.layout.payload_elems * 2 * (job.n_models + 1) * 1.05
+    result = None
+    try:
+        ok = torch.ones(1, device=device)
+        if rank == 0:
+            work.mkdir(parents=True, exist_ok=True)
+            if shutil.disk_usage(work).free < need:
+                ok.zero_()
+        if dist is not None:
+            dist.broadcast(ok, 0)
+        if not bool(ok.item()):
+            return {"skipped": f"{args.e2e_dir} has less than {need / 1e9:.0f} GB free"}
+        t0 = time.perf_counter()
+        if rank == 0:
+            write_checkpoints(job, work)
+        if dist is not None:
+            dist.barrier()
+        gen_s = time.perf_counter() - t0
+        models = [amd.model(str(work / f"m{m}.safetensors")) for m in range(job.n_models)]
+        if job.recipe == "ties":
+            recipe = amd.add_difference(models[0], amd.ties_sum(*[amd.subtract(m, models[0]) for m in models[1:]], k=0.2), alpha=1.0) | models[0]
+        elif job.recipe == "navg":
+            recipe = amd.n_average(*models)
+        else:
+            recipe = amd.weighted_sum(models[0], models[1], alpha=0.5)
+        from sd_mecha_amd import merging
+        out = work / "out.safetensors"
+        times, stats = [], {}
+        for _ in range(args.e2e_reps):
+            if rank == 0 and out.exists():
+                out.unlink()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            amd.merge(recipe, output=str(out), output_dtype=torch.bfloat16, merge_device=str(device),
+                      total_buffer_size=int(args.e2e_buffer_gib * 2 ** 30))
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            times.append(float(t.item()))
+            stats = dict(merging.last_stats)
+        link = link_rate(device)
+        if rank == 0:
+            best = min(times)
+            in_bytes = sum(numel(s) * (8 if d.startswith("int") else 2) for _, s, d in job.manifest) * job.n_models
+            out_bytes = sum(numel(s) for _, s, _ in job.manifest) * 2
+            # every rank has its own link: the slower direction, at the measured pinned rate, over the share of one rank
+            bound = max(in_bytes / world / (link["h2d"] * 1e9), out_bytes / world / (link["d2h"] * 1e9))
+            result = {
+                "what": "merge() wall time, first read to close(): .safetensors on tmpfs -> pinned staging -> H2D -> kernels -> D2H -> one .safetensors on tmpfs",
+                "seconds": round(best, 4), "all_seconds": [round(x, 4) for x in times], "merged_GBs": round((in_bytes + out_bytes) / best / 1e9, 2),
+                "h2d_GBs": round(in_bytes / best / 1e9, 2), "d2h_GBs": round(out_bytes / best / 1e9, 2),
+                "link_peak_GBs_per_gpu": link, "host_link_frac": round(bound / best, 4), "sink": "file:tmpfs",
+                "scaling": "strong" if world > 1 else "n/a", "n_gpus": world, "keys": len(job.manifest),
+                "fused_keys_rank0": stats.get("fused_keys"), "per_key_path_keys_rank0": stats.get("generic_keys"),
+                "total_buffer_size_gib_per_rank": args.e2e_buffer_gib, "generate_seconds": round(gen_s, 1),
+                "phases_rank0_s": {k: round(v, 3) for k, v in stats.items() if isinstance(v, float)},
+            }
+    finally:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(work, ignore_errors=True)
+    return result
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never does) and pass its exit code on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse(args, rank, world):
+    """No GPU: the ranks meet over gloo, agree on who they are, rank 0 prints what it saw."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0"))})
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks": seen}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse:
+        return rehearse(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -188,6 +359,8 @@ def main():
         dist.all_reduce(total_bytes, op=dist.ReduceOp.SUM)
     elapsed_max = float(t_max.item())
     value = float(total_bytes.item()) / elapsed_max / 1e9
+
+    e2e = None if args.no_e2e else e2e_leg(job, args, rank, world, dist, device)
 
     if rank == 0:
         # dominant kernel by summed time; its own algorithmic bytes per launch (DESIGN.md "kernels")
@@ -232,6 +405,8 @@ def main():
                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ties stats")
             line["ties_select"] = {"pairs": len(job.layout.keys) * (job.n_models - 1), "pairs_fell_back_to_radix": failed.value,
                                    "elements_in_ambiguous_lists": amb.value}
+        if e2e is not None:
+            line["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(job, args.cpu_seconds)
         print(json.dumps(line), flush=True)

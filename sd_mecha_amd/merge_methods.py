@@ -311,12 +311,13 @@ def add_difference_ties(base, *models, k: float = 1.0, alpha=1.0, vote_sgn: bool
     return (out, thr) if return_thresholds else out
 
 
-def dare_draw_masks(seed: int, probability: float, n_models: int, numel: int, device) -> torch.Tensor:
+def dare_draw_masks(seed: Optional[int], probability: float, n_models: int, numel: int, device) -> torch.Tensor:
     """The keep masks the reference draws with torch's CPU generator (ties.py:29-33, :63-64), bit-packed,
-    drawn on the host by libmecha_hip and uploaded: int32 [n_models, ceil(numel / 32)]."""
+    drawn on the host by libmecha_hip and uploaded: int32 [n_models, ceil(numel / 32)].  seed None or < 0: the stream of a
+    generator that was never seeded."""
     words = (numel + 31) // 32
     host = torch.empty((n_models, words), dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.empty((n_models, words), dtype=torch.int32)
-    _lib.check(_lib.lib().mecha_dare_draw_masks_host(int(seed) & 0xFFFFFFFFFFFFFFFF, float(probability), n_models, numel, host.data_ptr()),
+    _lib.check(_lib.lib().mecha_dare_draw_masks_host(_dare_seed(seed) & 0xFFFFFFFFFFFFFFFF, float(probability), n_models, numel, host.data_ptr()),
                "mecha_dare_draw_masks_host")
     return host.to(device, non_blocking=False)
 

@@ -319,6 +319,10 @@ class HipBackend:
             raise RuntimeError(f"merge_device={device!r}: the MI355X backend runs on a ROCm device only (there is no CPU path)")
         if not torch.cuda.is_available():
             raise RuntimeError("no ROCm device is visible; the MI355X backend has no CPU fallback")
+        if self.device.index is not None:
+            torch.cuda.set_device(self.device)               # one process per GPU: this rank's device becomes the current one
+        else:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.lib()
         self.methods = mm
 

@@ -347,7 +347,10 @@ def test_host_validation(amd):
         amd.n_average(a, a.to(torch.bfloat16))
     from sd_mecha_amd import _lib
     with pytest.raises(_lib.MechaError):
-        amd.ties_sum(a, a, k=1.5)
+        amd.ties_sum(a, a, k=-0.5)               # the rank would exceed numel: torch.kthvalue raises in the reference
+    # k > 1 is legal: kth = max(int((1 - k) * numel), 1) clamps the rank to 1 (ties.py:129), i.e. everything is kept
+    b = torch.randn(16, device="cuda")
+    assert torch.equal(amd.ties_sum(a, b, k=1.5), amd.ties_sum(a, b, k=1.0))
 
 
 # ------------------------------------------------------------------ batched (scheduler) entry points
