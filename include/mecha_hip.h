@@ -147,6 +147,17 @@ int mecha_add_difference_ties(const void *base, const void *const *models, int n
                               int vote_sgn, float *thresholds_out, void *workspace,
                               size_t workspace_bytes, uint32_t *flags, void *stream);
 
+/* The same with NO caller workspace and no allocation of any kind.  No counterpart in the reference: it is for callers
+ * that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The kernels
+ * use a scratch array that is part of the library's device image (8 MiB per GPU the library runs on, held until the process
+ * ends).  Limits: 1..8 models, numel <= 2^26 (every SDXL / FLUX key); beyond them the call fails with MECHA_ERR_ARG and a
+ * message naming the limit.  Calls no hipMalloc / hipFree or allocating routine; the first call on a device looks the
+ * array's address up (hipGetSymbolAddress).  Every call on a GPU shares that GPU's array (the call clears what must start
+ * at zero): calls that OVERLAP on one GPU -- two streams, two threads -- race; serialise them or use the workspace form. */
+int mecha_add_difference_ties_noalloc(const void *base, const void *const *models, int n_models, void *out,
+                                      int64_t numel, int in_dtype, int out_dtype, double k, float alpha,
+                                      int vote_sgn, float *thresholds_out, uint32_t *flags, void *stream);
+
 /* Diagnostics of the last TIES call that used `workspace` (sized for the same n_models,
  * n_segments (1 for the per-key entry points), total_elems (numel for per-key)): how many
  * (key, delta) pairs fell back to the radix select, and how many elements went through the

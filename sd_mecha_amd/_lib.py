@@ -69,6 +69,7 @@ SIGNATURES = {
     "mecha_ties_select_stats": (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_p]),
     "mecha_ties_sum": (c_i, [c_p, c_i, c_p, c_i64, c_i, c_i, c_d, c_i, c_p, c_p, c_sz, c_p, c_p]),
     "mecha_add_difference_ties": (c_i, [c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_d, c_f, c_i, c_p, c_p, c_sz, c_p, c_p]),
+    "mecha_add_difference_ties_noalloc": (c_i, [c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_d, c_f, c_i, c_p, c_p, c_p]),
     "mecha_ties_sum_with_dropout": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_d, c_i, c_f, c_i, c_p, c_p, c_sz, c_p, c_p]),
     "mecha_ties_extended_workspace_bytes": (c_sz, [c_i, c_i64, c_i64]),
     "mecha_ties_sum_extended": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i64, c_i, c_i, c_d, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_sz, c_p, c_p]),

@@ -1595,6 +1595,47 @@ int run_ties(const TiesCall &c) {
     return MECHA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ allocation-free entry point
+// mecha_add_difference_ties_noalloc runs the same kernels on a workspace that lives in the library's own device image:
+// callers that cannot call hipMalloc (HIP graph capture, serving loops, harnesses that forbid it) need no workspace.
+// Every GPU the library runs on holds its own copy of the array until the process ends.  In HOST code `scratch` is only a
+// stand-in for the symbol, not a device address: the per-device address comes from hipGetSymbolAddress, once per device,
+// and only that pointer is handed to kernels and memsets.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)8 << 20;
+constexpr int NOALLOC_MAX_MODELS = 8;
+constexpr int64_t NOALLOC_MAX_NUMEL = (int64_t)1 << 26;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+
+}  // namespace
+
+#include <mutex>
+
+// File scope, outside the anonymous namespace: a `static __device__` variable that host code names is given an external
+// device symbol by the compiler, which is how hipGetSymbolAddress finds it; inside an anonymous namespace the device symbol
+// stays local and the runtime aborts ("Cannot create GlobalVar Obj", tools/scratch_probe/).
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[NOALLOC_MAX_DEVICES];          // device address of `scratch` on each device, 0 = not looked up yet
+
+// The current device's copy of `scratch`; looked up on the first call on that device (with it current).
+int scratch_for_current_device(void **out) {
+    int dev = -1;
+    MECHA_CHECK_HIP(hipGetDevice(&dev));
+    MECHA_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "device index %d outside 0..%d", dev, NOALLOC_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void *ptr = nullptr;
+        MECHA_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        MECHA_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return MECHA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1641,6 +1682,26 @@ int mecha_add_difference_ties(const void *base, const void *const *models, int n
     c.out_dt = out_dtype; c.k = k; c.alpha = alpha; c.vote_sgn = vote_sgn; c.thresholds_out = thresholds_out;
     c.workspace = workspace; c.workspace_bytes = workspace_bytes; c.flags = flags; c.stream = stream;
     return run_ties(c);
+}
+
+int mecha_add_difference_ties_noalloc(const void *base, const void *const *models, int n_models, void *out, int64_t numel,
+                                      int in_dtype, int out_dtype, double k, float alpha, int vote_sgn, float *thresholds_out,
+                                      uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(base != nullptr, "base is NULL");
+    MECHA_REQUIRE(n_models >= 1 && n_models <= NOALLOC_MAX_MODELS, "the allocation-free entry point takes 1..%d models (got %d): "
+                  "use mecha_add_difference_ties with a caller workspace", NOALLOC_MAX_MODELS, n_models);
+    MECHA_REQUIRE(numel >= 0 && numel <= NOALLOC_MAX_NUMEL, "the allocation-free entry point takes keys of up to %lld elements (got %lld): "
+                  "use mecha_add_difference_ties with a caller workspace", (long long)NOALLOC_MAX_NUMEL, (long long)numel);
+    const size_t need = layout(n_models, 1, numel).total;
+    MECHA_REQUIRE(need <= NOALLOC_SCRATCH_BYTES, "the key needs %zu bytes of workspace, the built-in scratch holds %zu", need, NOALLOC_SCRATCH_BYTES);
+    void *ptr = nullptr;
+    const int st = scratch_for_current_device(&ptr);
+    if (st != MECHA_OK) return st;
+    TiesCall c{};
+    c.base = base; c.inputs = models; c.n_deltas = n_models; c.out = out; c.numel = numel; c.in_dt = in_dtype;
+    c.out_dt = out_dtype; c.k = k; c.alpha = alpha; c.vote_sgn = vote_sgn; c.thresholds_out = thresholds_out;
+    c.workspace = ptr; c.workspace_bytes = NOALLOC_SCRATCH_BYTES; c.flags = flags; c.stream = stream;
+    return run_ties(c);       // clears the part of the workspace that must start at zero (state, counters, histograms) itself
 }
 
 int mecha_ties_sum_with_dropout(const void *const *deltas, int n_models, const uint32_t *keep_bits, void *out, int64_t numel,

@@ -1,0 +1,90 @@
+"""GPU: the allocation-free entry point mecha_add_difference_ties_noalloc (no counterpart in the reference; for callers
+that cannot call hipMalloc) against the workspace form mecha_add_difference_ties, through the C ABI, bit for bit: outputs,
+thresholds and flag words, on two calls in a row that share the built-in scratch array -- the second with a smaller input --
+and the limits it must refuse."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _call_pair(L, _lib, n_models, numel, seed, k=0.2, alpha=1.0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    base = torch.empty(numel, dtype=dtype, device="cuda").normal_(0.0, 0.02, generator=g)
+    models = [torch.empty(numel, dtype=dtype, device="cuda").normal_(0.0, 0.02, generator=g) for _ in range(n_models)]
+    code = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float32: _lib.F32}[dtype]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptrs = _lib.ptr_array([m.data_ptr() for m in models])
+
+    want = torch.empty(numel, dtype=dtype, device="cuda")
+    want_thr = torch.zeros(n_models, dtype=torch.float32, device="cuda")
+    want_flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(L.mecha_ties_workspace_bytes(n_models, numel), dtype=torch.uint8, device="cuda")
+    _lib.check(L.mecha_add_difference_ties(base.data_ptr(), ptrs, n_models, want.data_ptr(), numel, code, code, k, alpha, 0,
+                                           want_thr.data_ptr(), ws.data_ptr(), ws.numel(), want_flags.data_ptr(), stream), "workspace form")
+
+    got = torch.full((numel,), float("nan"), dtype=dtype, device="cuda")
+    got_thr = torch.zeros(n_models, dtype=torch.float32, device="cuda")
+    got_flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    _lib.check(L.mecha_add_difference_ties_noalloc(base.data_ptr(), ptrs, n_models, got.data_ptr(), numel, code, code, k, alpha, 0,
+                                                   got_thr.data_ptr(), got_flags.data_ptr(), stream), "allocation-free form")
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() == before
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n_models, numel)
+    assert torch.equal(got_thr.view(torch.int32), want_thr.view(torch.int32))
+    assert int(got_flags.item()) == int(want_flags.item()) == 0
+    return got
+
+
+def test_noalloc_matches_workspace_form_twice_in_a_row():
+    from sd_mecha_amd import _lib
+    L = _lib.lib()
+    # the first call leaves its state, histograms and ambiguous lists in the shared scratch; the second, smaller one must not see them
+    _call_pair(L, _lib, 3, 1280 * 1280 + 77, seed=1)
+    _call_pair(L, _lib, 3, 320 * 320 + 5, seed=2)
+    _call_pair(L, _lib, 7, 640 * 640, seed=3, k=0.5, alpha=0.7)
+    _call_pair(L, _lib, 1, 4096, seed=4)                                   # a key the sample pass solves whole
+    _call_pair(L, _lib, 2, 3000, seed=5, dtype=torch.float16)
+
+
+def test_noalloc_non_finite_flag_and_oracle():
+    """A NaN input raises bit 0 of the flag word like the workspace form; a clean key equals the CPU oracle."""
+    from oracle import oracle as O
+    from sd_mecha_amd import _lib
+    L = _lib.lib()
+    O.build()
+    rng = np.random.default_rng(9)
+    n = 50_000
+    bits = [O.from_f32(rng.normal(0, 0.02, size=n).astype(np.float32), "bfloat16") for _ in range(4)]
+    f32 = [O.to_f32(b, "bfloat16") for b in bits]
+    dev = [torch.from_numpy(b.view(np.int16).copy()).view(torch.bfloat16).cuda() for b in bits]
+    out = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptrs = _lib.ptr_array([m.data_ptr() for m in dev[1:]])
+    _lib.check(L.mecha_add_difference_ties_noalloc(dev[0].data_ptr(), ptrs, 3, out.data_ptr(), n, _lib.BF16, _lib.BF16, 0.2, 1.0, 0,
+                                                   None, flags.data_ptr(), stream), "allocation-free form")
+    want = O.from_f32(O.add_difference_ties(f32[0], f32[1:], k=0.2, alpha=1.0), "bfloat16")
+    assert np.array_equal(out.cpu().view(torch.int16).numpy().view(np.uint16), want)
+    assert int(flags.item()) == 0
+    dev[2][123] = float("nan")
+    _lib.check(L.mecha_add_difference_ties_noalloc(dev[0].data_ptr(), ptrs, 3, out.data_ptr(), n, _lib.BF16, _lib.BF16, 0.2, 1.0, 0,
+                                                   None, flags.data_ptr(), stream), "allocation-free form")
+    assert int(flags.item()) & _lib.FLAG_INPUT_NONFINITE
+
+
+def test_noalloc_refuses_sizes_beyond_its_scratch():
+    from sd_mecha_amd import _lib
+    L = _lib.lib()
+    a = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptrs9 = _lib.ptr_array([a.data_ptr()] * 9)
+    st = L.mecha_add_difference_ties_noalloc(a.data_ptr(), ptrs9, 9, a.data_ptr(), 64, _lib.BF16, _lib.BF16, 0.2, 1.0, 0, None, None, stream)
+    assert st < 0 and b"1..8 models" in L.mecha_last_error()
+    st = L.mecha_add_difference_ties_noalloc(a.data_ptr(), ptrs9, 3, a.data_ptr(), (1 << 26) + 8, _lib.BF16, _lib.BF16, 0.2, 1.0, 0, None, None, stream)
+    assert st < 0 and b"elements" in L.mecha_last_error()
