@@ -106,12 +106,14 @@ __device__ __forceinline__ void compute8(const EwParams &p, int64_t i, int valid
 template <int OP, int IN_DT, int OUT_DT, bool VEC, bool HAS_OUT>
 __global__ __launch_bounds__(MECHA_BLOCK) void ew_kernel(EwParams p, void *out, int64_t total,
                                                           const mecha_segment *segs, int n_segs, uint32_t *flags) {
-    // each block sweeps ONE contiguous chunk of the range (measured +17 % over a grid-stride loop, tools/stream_bench.hip)
+    // FLAT grid: one 16-byte vector position per thread, one block per 256 of them, no loop.  On gfx9 loads and stores share
+    // the one in-order vmcnt counter, so inside a loop every wait for the next loads also waits for the previous stores'
+    // acknowledgements; a wave that stores and ends does not.  Measured on the SDXL x4 footprint (tools/stream_bench3.hip,
+    // profiles/r02_stream_bench3.txt): 6.0 TB/s for 4 reads : 1 write and 6.4 TB/s for a copy, against 5.1-5.2 TB/s for every
+    // looped shape (chunk per block, grid-stride, 1-4 vectors in flight, grids of 1024-16384).
     const int64_t n_vec = (total + 7) >> 3;
-    const int64_t per_block = ((n_vec + gridDim.x - 1) / gridDim.x + MECHA_BLOCK - 1) / MECHA_BLOCK * MECHA_BLOCK;
-    const int64_t v_begin = (int64_t)blockIdx.x * per_block;
-    const int64_t v_end = (v_begin + per_block < n_vec) ? v_begin + per_block : n_vec;
-    for (int64_t v = v_begin + threadIdx.x; v < v_end; v += MECHA_BLOCK) {
+    const int64_t v = (int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x;
+    if (v < n_vec) {
         const int64_t i = v << 3;
         const int valid = (total - i >= 8) ? 8 : (int)(total - i);
         float r[8];
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ew_kernel(EwParams p, void *out, 
             uint32_t *word = flags;
             if (n_segs > 0) {
                 const int sidx = find_segment(segs, n_segs, i);
-                if (sidx < 0) continue;
+                if (sidx < 0) return;
                 word = flags + sidx;
                 const int64_t seg_end = segs[sidx].offset + segs[sidx].numel;
                 if (seg_end - i < valid) {
@@ -165,8 +167,8 @@ int launch_ew(EwParams &p, void *out, int64_t total, int in_dt, int out_dt, cons
         vec = vec && mecha_aligned16(p.in[m]);
     }
     const int64_t n_vec = (total + 7) >> 3;
-    int64_t blocks = (n_vec + MECHA_BLOCK - 1) / MECHA_BLOCK;
-    if (blocks > MECHA_MAX_GRID) blocks = MECHA_MAX_GRID;
+    const int64_t blocks = (n_vec + MECHA_BLOCK - 1) / MECHA_BLOCK;
+    MECHA_REQUIRE(blocks <= 0x7fffffff, "numel %lld is beyond one launch (2^31 - 1 blocks of 2048 elements)", (long long)total);
     dim3 grid((unsigned)blocks), block(MECHA_BLOCK);
     hipStream_t s = static_cast<hipStream_t>(stream);
     MECHA_DISPATCH_DTYPES(in_dt, out_dt, {

@@ -60,6 +60,8 @@ struct SelectState {                       // per (key, delta), 64 bytes
 struct SelectCounts { unsigned long long below, eq_lo; };
 struct TiesGlobals { uint32_t n_failed; uint32_t pad; unsigned long long n_amb; unsigned long long n_hit; };
 
+struct TileRec { long long elem; int seg; int valid; };     // first element of the tile inside the arena, its key, its element count
+
 struct TiesParams {
     const void *base;                      // nullptr: inputs are deltas
     const void *in[TIES_MAX_DELTAS];       // models (base mode) or deltas
@@ -72,6 +74,7 @@ struct TiesParams {
     mecha_segment seg0;                    // per key: the one segment
     int n_segs;
     const long long *tile_start;           // batched: device prefix of tiles per segment [n_segs + 1]
+    const struct TileRec *tile_rec;        // batched: one record per tile (flat-grid kernels); nullptr per key
     long long total_tiles;
     SelectState *state;                    // [n_segs * n_deltas]
     uint32_t *hist;                        // [n_segs * n_deltas * TIES_BINS]
@@ -899,44 +902,46 @@ __device__ __forceinline__ int sign_i32(int v) {
 
 template <int N, int DT, int ODT>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
-    const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
-    const long long t0 = (long long)blockIdx.x * chunk;
-    const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
+    // FLAT grid: one block per HALF tile (256 lanes x one 16-byte vector position), no loop -- a wave loads, stores and ends.
+    // Loads and stores share gfx9's one in-order vmcnt counter, so a looping wave waits for its previous stores whenever it
+    // waits for its next loads; with a write stream every looped shape stops at 5.1-5.2 TB/s where this one reaches 6.0
+    // (tools/stream_bench3.hip, profiles/r02_stream_bench3.txt).  The block finds its tile through one 16-byte record.
     __shared__ float recip[16];                    // correctly rounded 1 / count, [0] = +inf
     if (threadIdx.x < 16) recip[threadIdx.x] = 1.0f / (float)threadIdx.x;
-    __syncthreads();
-    TileCursor cur;
-    float thr[N], amb_hi[N];
-    bool key_ok = false, any_amb = false;
-#pragma unroll
-    for (int d = 0; d < N; d++) { thr[d] = 0.0f; amb_hi[d] = -1.0f; }
+    const long long t = (long long)(blockIdx.x >> 1);
+    const int u = (int)(blockIdx.x & 1);
+    TileRec rec;
+    if (p.tile_rec != nullptr) rec = p.tile_rec[t];
+    else {
+        const long long left = p.seg0.numel - t * TIES_TILE;
+        rec = TileRec{t * TIES_TILE, 0, (int)(left < TIES_TILE ? left : TIES_TILE)};
+    }
+    if (rec.valid < TIES_TILE) return;                                                 // ties_merge_kernel's tile
+    const int64_t e = rec.elem + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
     const uint16_t *base = static_cast<const uint16_t *>(p.base);
+    // every load is issued before the key's thresholds (a second, dependent read) are needed
+    u32x4 rv[N];
+    const u32x4 rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + e));
+#pragma unroll
+    for (int m = 0; m < N; m++) rv[m] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(p.in[m]) + e));
+    float thr[N], amb_hi[N];
+    bool key_ok = true, any_amb = false;
+    {
+        const SelectState *st = p.state + (int64_t)rec.seg * N;
+#pragma unroll
+        for (int d = 0; d < N; d++) {
+            thr[d] = prov_threshold(st[d]);
+            amb_hi[d] = (st[d].mode == MODE_AMBIG) ? __uint_as_float(st[d].amb_hi) : -1.0f;
+            key_ok = key_ok && (thr[d] >= 0x1p-90f);
+            any_amb = any_amb || (amb_hi[d] >= 0.0f);
+        }
+    }
+    if (!key_ok) return;                                                                // ties_merge_kernel's key (same test there)
+    __syncthreads();                                                                    // recip[]
     const f32x2 zero2 = {0.0f, 0.0f};
     const f32x2 alpha2 = {x.alpha, x.alpha};
-    for (long long t = t0; t < t1; t++) {
-        const int prev = cur.s;
-        cursor_seek(p, t, cur);
-        if (cur.s != prev) {
-            const SelectState *st = p.state + (int64_t)cur.s * N;
-            key_ok = true; any_amb = false;
-#pragma unroll
-            for (int d = 0; d < N; d++) {
-                thr[d] = prov_threshold(st[d]);
-                amb_hi[d] = (st[d].mode == MODE_AMBIG) ? __uint_as_float(st[d].amb_hi) : -1.0f;
-                key_ok = key_ok && (thr[d] >= 0x1p-90f);
-                any_amb = any_amb || (amb_hi[d] >= 0.0f);
-            }
-        }
-        if (!key_ok || (t - cur.first + 1) * TIES_TILE > cur.seg.numel) continue;     // ties_merge_kernel's tile
-        bool bad = false, bad_o = false, hit_any = false;
-#pragma unroll 1
-        for (int u = 0; u < 2; u++) {
-            const int64_t e = cur.seg.offset + (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
-            // every load of this position is issued before the first one is consumed
-            u32x4 rv[N];
-            const u32x4 rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + e));
-#pragma unroll
-            for (int m = 0; m < N; m++) rv[m] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(p.in[m]) + e));
+    {
+        {
             f32x2 b2[4];
             unpack_pairs<DT>(rb, b2);
             f32x2 poison = zero2;                  // fma(x, 0, poison): 0 while every input is finite, NaN after inf / NaN
@@ -1060,17 +1065,15 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
             for (int q = 0; q < 4; q++) out_poison = __builtin_elementwise_fma(r2[q], zero2, out_poison);
             const float r[8] = {r2[0].x, r2[0].y, r2[1].x, r2[1].y, r2[2].x, r2[2].y, r2[3].x, r2[3].y};
             store8<ODT, true>(out, e, r);
-            bad |= (poison.x != poison.x) | (poison.y != poison.y);
-            bad_o |= (out_poison.x != out_poison.x) | (out_poison.y != out_poison.y);
+            const bool bad = (poison.x != poison.x) | (poison.y != poison.y);
+            const bool bad_o = (out_poison.x != out_poison.x) | (out_poison.y != out_poison.y);
             if (hit) {
                 const unsigned long long slot = atomicAdd(&p.globals->n_hit, 1ull);
-                if (slot < p.amb_capacity) { p.hit_elem[slot] = e; p.hit_seg[slot] = (uint32_t)cur.s; }
+                if (slot < p.amb_capacity) { p.hit_elem[slot] = e; p.hit_seg[slot] = (uint32_t)rec.seg; }
             }
-            hit_any |= hit;
+            if ((bad | bad_o) && flags != nullptr)
+                atomicOr(flags + (p.tile_start == nullptr ? 0 : rec.seg), (bad ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_o ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
         }
-        if ((bad | bad_o) && flags != nullptr)
-            atomicOr(flags + (p.tile_start == nullptr ? 0 : cur.s), (bad ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_o ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
-        (void)hit_any;
     }
 }
 
@@ -1165,6 +1168,18 @@ __global__ __launch_bounds__(1024) void ties_tile_index_kernel(const mecha_segme
     __syncthreads();
     long long run = part[threadIdx.x];
     for (int i = lo; i < hi; i++) { tile_start[i] = run; run += (segs[i].numel + TIES_TILE - 1) / TIES_TILE; }
+}
+
+// One record per tile for the flat-grid kernels (one block per segment; a block of the flat merge kernel then needs ONE
+// 16-byte read to know where it is, instead of a binary search over the tile prefix).
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_tile_records_kernel(const mecha_segment *segs, const long long *tile_start, TileRec *rec) {
+    const int s = blockIdx.x;
+    const mecha_segment seg = segs[s];
+    const long long first = tile_start[s], n = tile_start[s + 1] - first;
+    for (long long i = threadIdx.x; i < n; i += MECHA_BLOCK) {
+        const long long left = seg.numel - i * TIES_TILE;
+        rec[first + i] = TileRec{seg.offset + i * TIES_TILE, s, (int)(left < TIES_TILE ? left : TIES_TILE)};
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ model-stock factor
@@ -1318,7 +1333,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_apply_kernel(TiesParam
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    size_t tile_start_off, state_off, counts_off, fill_off, globals_off, hist_off, amb_elem_off, amb_bits_off, amb_sd_off,
+    size_t tile_start_off, tile_rec_off, state_off, counts_off, fill_off, globals_off, hist_off, amb_elem_off, amb_bits_off, amb_sd_off,
         hit_elem_off, hit_seg_off, total;
     size_t amb_capacity;
 };
@@ -1328,6 +1343,9 @@ WorkspaceLayout layout(int n_deltas, int n_segs, int64_t total_elems) {
     w.amb_capacity = n_sd * AMB_BASE_CAP + (size_t)n_deltas * ((size_t)(total_elems > 0 ? total_elems : 0) / AMB_DIV + 1);
     size_t off = 0;
     w.tile_start_off = off; off = align_up(off + sizeof(long long) * ((size_t)n_segs + 1), 256);
+    // batched only (n_segs > 1 or an arena): at most total_elems / TILE + n_segs tiles
+    const size_t max_tiles = (size_t)(total_elems > 0 ? total_elems : 0) / TIES_TILE + (size_t)n_segs;
+    w.tile_rec_off = off;   off = align_up(off + sizeof(TileRec) * max_tiles, 256);
     w.state_off = off;      off = align_up(off + sizeof(SelectState) * n_sd, 256);
     w.counts_off = off;     off = align_up(off + sizeof(SelectCounts) * n_sd, 256);
     w.fill_off = off;       off = align_up(off + sizeof(uint32_t) * n_sd, 256);
@@ -1416,7 +1434,8 @@ void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float 
 }
 
 template <int N, int DT>
-void launch_merge_full(const TiesParams &p, const MergeExtra &x, unsigned grid, void *out, uint32_t *flags, hipStream_t s) {
+void launch_merge_full(const TiesParams &p, const MergeExtra &x, unsigned /*looped_grid*/, void *out, uint32_t *flags, hipStream_t s) {
+    const unsigned grid = (unsigned)(2 * p.total_tiles);          // flat: one block per half tile
     if (p.out_dt == MECHA_BF16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_BF16>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
     else if (p.out_dt == MECHA_F16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F16>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
     else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F32>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
@@ -1523,6 +1542,7 @@ int run_ties(const TiesCall &c) {
     p.seg0 = mecha_segment{0, batched ? 0 : c.numel};
     p.n_segs = n_segs;
     p.tile_start = batched ? reinterpret_cast<const long long *>(ws + w.tile_start_off) : nullptr;
+    p.tile_rec = batched ? reinterpret_cast<const TileRec *>(ws + w.tile_rec_off) : nullptr;
     p.total_tiles = total_tiles;
     p.state = reinterpret_cast<SelectState *>(ws + w.state_off);
     p.hist = reinterpret_cast<uint32_t *>(ws + w.hist_off);
@@ -1541,9 +1561,14 @@ int run_ties(const TiesCall &c) {
     MECHA_REQUIRE(n_sd < ((size_t)1 << 31), "too many (key, delta) pairs");
     // state, fill, globals are contiguous up to the histograms: one memset clears them all
     MECHA_CHECK_HIP(hipMemsetAsync(ws + w.state_off, 0, w.amb_elem_off - w.state_off, s));
-    if (batched)
+    if (batched) {
+        MECHA_REQUIRE((size_t)total_tiles <= (size_t)(c.total_elems > 0 ? c.total_elems : 0) / TIES_TILE + (size_t)n_segs,
+                      "segments hold more tiles than the workspace was sized for");
         MECHA_LAUNCH(MK_TIES_INDEX, ties_tile_index_kernel, dim3(1), dim3(1024), 0, s, c.segs_dev, n_segs,
                      reinterpret_cast<long long *>(ws + w.tile_start_off));
+        MECHA_LAUNCH(MK_TIES_INDEX, ties_tile_records_kernel, dim3((unsigned)n_segs), dim3(MECHA_BLOCK), 0, s, c.segs_dev,
+                     reinterpret_cast<const long long *>(ws + w.tile_start_off), reinterpret_cast<TileRec *>(ws + w.tile_rec_off));
+    }
     unsigned grid = (unsigned)(total_tiles < MECHA_MAX_GRID ? total_tiles : MECHA_MAX_GRID);
     const double one_minus_k = 1.0 - c.k;
     MergeExtra x{};

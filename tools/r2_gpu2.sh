@@ -1,0 +1,17 @@
+# GPU suite, then the HBM-resident bench lines (no e2e / cpu legs) of the four streaming workloads
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/r2
+cd $R
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r2/gpu_tests.txt 2>&1; rc=$?
+tail -5 gpurun_out/r2/gpu_tests.txt
+if [ $rc -ne 0 ]; then echo "gpu tests failed rc=$rc"; exit $rc; fi
+for w in sdxl_ties sdxl_navg flux_navg flux_ties; do
+  timeout -k 10 300 python bench.py --workload $w --steps 10 --warmup 3 --no-e2e --no-cpu-baseline > gpurun_out/r2/bench_$w.json 2> gpurun_out/r2/bench_$w.err; rc=$?
+  if [ $rc -ne 0 ]; then echo "bench $w failed rc=$rc"; tail -5 gpurun_out/r2/bench_$w.err; exit $rc; fi
+  python - <<PY
+import json
+d = json.load(open("gpurun_out/r2/bench_$w.json"))
+print("$w", d["value"], "GB/s", d["ms_per_step"], "ms", d["roofline"]["kernel"], d["roofline"]["frac"], {k: v["ms_per_step"] for k, v in d["kernels"].items() if v["ms_per_step"] > 0.05})
+PY
+done
