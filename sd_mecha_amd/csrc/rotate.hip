@@ -535,7 +535,30 @@ __global__ __launch_bounds__(256) void rot_polar_scale_kernel(float *x, int64_t 
     }
 }
 
-int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, int64_t c, double *scal, float *slabs, int *iters_out, hipStream_t s) {
+// X (r x c row-major) <- (I - 1 1^T / r) X: every column loses its mean.  For a fully centred wide key the all-ones vector is
+// the exact left null vector of both matrices the wide case takes a polar factor of (1^T Bc = 0; N^T = (Bc Qb)^T Ac with
+// Bc Qb symmetric and 1 in its null space), but fp32 rounding leaves ~1e-8 of it in X and the iteration grows anything that
+// small 3.86x per step -- back to a singular value of order 1 after 14 steps, along a direction made of rounding noise.
+// Removing it every few steps keeps the zero singular value at rounding level, so the factor is the one of the rank-(r - 1)
+// matrix (the minimum-norm member of the reference's family, DESIGN.md "rotate: reference indeterminacy").
+// One block per 64 columns: 4 row groups x 64 columns, fp64 partial sums through LDS.
+__global__ __launch_bounds__(256) void rot_deflate_ones_kernel(float *x, int64_t r, int64_t c) {
+    __shared__ double part[4][64];
+    const int col_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + col_l;
+    double sum = 0.0;
+    if (col < c)
+        for (int64_t i = grp; i < r; i += 4) sum += (double)x[i * c + col];
+    part[grp][col_l] = sum;
+    __syncthreads();
+    const float mean = (float)((part[0][col_l] + part[1][col_l] + part[2][col_l] + part[3][col_l]) / (double)r);
+    if (col < c)
+        for (int64_t i = grp; i < r; i += 4) x[i * c + col] -= mean;
+}
+constexpr int POLAR_DEFLATE_EVERY = 3;
+
+int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, int64_t c, double *scal, float *slabs, int *iters_out, hipStream_t s,
+                        bool deflate_ones = false) {
     float *cur = X, *nxt = tmp;
     const int64_t rr = r * r;
     const unsigned nb = (unsigned)((rr + 255) / 256 < 1024 ? (rr + 255) / 256 : 1024);
@@ -561,6 +584,8 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
         upd.axpy = cur; upd.axpy_a = ps.step[it].a; upd.axpy_b = 1.0f;
         gemm(Operand{G2, r, 1}, Operand{cur, c, 1}, nxt, r, c, r, slabs, upd, s);
         float *t = cur; cur = nxt; nxt = t;
+        if (deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == ps.n))
+            MECHA_LAUNCH(MK_ROT_NORMS, rot_deflate_ones_kernel, dim3((unsigned)((c + 63) / 64)), dim3(256), 0, s, cur, r, c);
     }
     if (iters_out) *iters_out += ps.n;
     if (cur != X) MECHA_CHECK_HIP(hipMemcpyAsync(X, cur, sizeof(float) * r * c, hipMemcpyDeviceToDevice, s));
@@ -658,12 +683,14 @@ int mecha_rotate_ex(const void *a, const void *b, void *out, int64_t n, int64_t 
         } else {
             // Qb^T = polar factor of Bc: orthonormal rows spanning the row space of Bc (= columns of b.mH)
             MECHA_CHECK_HIP(hipMemcpyAsync(qbt, bc, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-            if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, slabs, sweeps_out, s)) != MECHA_OK) return rc;
+            // fully centred (the default): both wide-case matrices have the all-ones vector as their exact left null vector
+            const bool deflate = centralization == 1.0f;
+            if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, slabs, sweeps_out, s, deflate)) != MECHA_OK) return rc;
             // T^T = Bc Qb =: P (n x n):  P[r][k] = sum_c Bc[r][c] Qb^T[k][c]
             gemm(Operand{bc, 1, p}, Operand{qbt, 1, p}, P, n, n, p, slabs, none, s);
             // N^T = P^T Ac (n x p):  N^T[k][i] = sum_r P[r][k] Ac[r][i];  N = U S W^T, Z := polar(N^T) = W U^T
             gemm(Operand{P, n, 1}, Operand{ac, p, 1}, z, n, p, n, slabs, none, s);
-            if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, slabs, sweeps_out, s)) != MECHA_OK) return rc;
+            if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, slabs, sweeps_out, s, deflate)) != MECHA_OK) return rc;
         }
         if (transform_out != nullptr) {
             MECHA_CHECK_HIP(hipMemcpyAsync(transform_out, qbt, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));

@@ -27,14 +27,14 @@ def test_rotate_golden(oracle):
             for cz in (1.0, 0.0):
                 want = f32_from_bits(g[f"{pre}_out_alpha{alpha}_cz{cz}"]).reshape(a.shape)
                 got = amd.rotate(ta, tb, alignment=1.0, alpha=alpha, centralization=cz).cpu().numpy()
-                rel = rotate_rel_error(oracle, a, b, got, want, cz)
+                rel = rotate_rel_error(oracle, a, b, got, want, cz, 1.0, alpha)
                 assert rel <= 1e-3, (pre, alpha, cz, rel)
         for alignment, alpha, cz in ROTATE_EXTRA_CASES:         # alignment 0 and -1 (svd.py:84-85, :177-183, :209-215)
             if rotate_case_undetermined(oracle, a.shape, alignment, alpha, cz):
                 continue
             want = f32_from_bits(g[f"{pre}_out_align{alignment}_alpha{alpha}_cz{cz}"]).reshape(a.shape)
             got = amd.rotate(ta, tb, alignment=alignment, alpha=alpha, centralization=cz).cpu().numpy()
-            rel = rotate_rel_error(oracle, a, b, got, want, cz, alignment)
+            rel = rotate_rel_error(oracle, a, b, got, want, cz, alignment, alpha)
             assert rel <= 1e-3, (pre, alignment, alpha, cz, rel)
         # the factor cache (svd.py:55-79): the second call reads the transform the first one saved (fp16, on the host)
         cache = amd.rotate.create_cache()
@@ -45,7 +45,7 @@ def test_rotate_golden(oracle):
             second, iters = amd.rotate(ta, tb, alignment=1.0, alpha=0.5, centralization=1.0, key="k", cache=cache, return_sweeps=True)
             assert iters == 0                                   # no Procrustes solve on a cache hit
             want = f32_from_bits(g[f"{pre}_out_cached_alpha0.5"]).reshape(a.shape)
-            rel = rotate_rel_error(oracle, a, b, second.cpu().numpy(), want, 1.0)
+            rel = rotate_rel_error(oracle, a, b, second.cpu().numpy(), want, 1.0, 1.0, 0.5)
             assert rel <= 1e-3, (pre, "cached", rel)
             again = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=1.0, key="k", cache=cache)
             rel = rotate_rel_error(oracle, a, b, again.cpu().numpy(), first.cpu().numpy(), 1.0)
@@ -92,8 +92,42 @@ def test_rotate_vs_oracle(oracle, shape, cz):
             continue
         want = oracle.rotate(a, b, alignment=alignment, alpha=alpha, centralization=cz)
         got = amd.rotate(ta, tb, alignment=alignment, alpha=alpha, centralization=cz)
-        rel = rotate_rel_error(oracle, a, b, got.cpu().numpy(), want, cz, alignment)
+        rel = rotate_rel_error(oracle, a, b, got.cpu().numpy(), want, cz, alignment, alpha)
         assert rel <= 1e-3, (shape, cz, alignment, alpha, rel)
+
+
+# SDXL's real shapes: the centred square 1280 x 1280 (one zero singular value), the wide 1280 x 5120 and
+# 640 x 2048, 3 x 3 convolutions as (out * in) x 9 with 102 400 and 1.6 M rows, and the 49408 x 1280 embedding.
+@pytest.mark.parametrize("shape,cz", [((1280, 1280), 1.0), ((1280, 5120), 1.0), ((640, 2048), 1.0), ((640, 2048), 0.0),
+                                      ((320, 320, 3, 3), 1.0), ((1280, 1280, 3, 3), 1.0), ((49408, 1280), 1.0)])
+def test_rotate_sdxl_shapes_vs_oracle(oracle, shape, cz):
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(1280 + len(shape) + shape[1])
+    a = oracle.to_f32(oracle.from_f32(rng.normal(0, 0.02, size=shape).astype(np.float32), "bfloat16"), "bfloat16")
+    b = oracle.to_f32(oracle.from_f32(rng.normal(0, 0.02, size=shape).astype(np.float32), "bfloat16"), "bfloat16")
+    want = oracle.rotate(a, b, alignment=1.0, alpha=0.0, centralization=cz)
+    ta, tb = torch.from_numpy(a).cuda().to(torch.bfloat16), torch.from_numpy(b).cuda().to(torch.bfloat16)
+    got = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=cz).cpu().numpy()
+    rel = rotate_rel_error(oracle, a, b, got, want, cz)
+    assert rel <= 1e-3, (shape, cz, rel)
+    n, p = oracle.rotate_shape_2d(shape)
+    a2, g2, b2 = (x.reshape(n, p).astype(np.float64) for x in (a, got, b))
+    ac, gc = a2 - a2.mean(0) * cz, g2 - b2.mean(0) * cz
+    if n > p + 1:
+        # tall: the centred output is the centred input times an orthogonal matrix -- Gram matrices agree
+        assert abs(np.linalg.norm(gc) / np.linalg.norm(ac) - 1.0) < 1e-4
+        rows = rng.choice(n, size=min(n, 512), replace=False)
+        ga, gg = ac[rows] @ ac[rows].T, gc[rows] @ gc[rows].T
+        assert np.linalg.norm(ga - gg) / np.linalg.norm(ga) < 1e-3
+    else:
+        # wide / square: the pass-through part.  Outside the row spaces of the centred a and b nothing may change except
+        # along the reference's one free direction: (got - a) restricted to that complement has rank <= 1 ... and the HIP
+        # path returns the minimum-norm member, for which it is zero
+        _, sv, vh = np.linalg.svd(np.vstack([ac, b2 - b2.mean(0) * cz]), full_matrices=False)
+        basis = vh[sv > sv[0] * 1e-6]
+        moved = gc - ac
+        outside = moved - (moved @ basis.T) @ basis
+        assert np.linalg.norm(outside) / np.linalg.norm(ac) < 1e-3, (shape, np.linalg.norm(outside) / np.linalg.norm(ac))
 
 
 def test_rotate_recipe_with_cache(oracle, tmp_path):
@@ -119,7 +153,7 @@ def test_rotate_recipe_with_cache(oracle, tmp_path):
         outs.append(res)
         for k in shapes:
             want = oracle.rotate(sds[0][k], sds[1][k], alignment=1.0, alpha=alpha, centralization=1.0)
-            rel = rotate_rel_error(oracle, sds[0][k], sds[1][k], res[k].cpu().numpy(), want, 1.0)
+            rel = rotate_rel_error(oracle, sds[0][k], sds[1][k], res[k].cpu().numpy(), want, 1.0, 1.0, alpha)
             assert rel <= 1e-3, (k, alpha, rel)
     assert set(cache) == {"w.tall", "w.wide", "w.conv"}          # 1-D keys take the lerp early-out before the cache (svd.py:46-47)
     assert all(v["transform"].dtype == torch.float16 for v in cache.values())
