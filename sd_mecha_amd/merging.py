@@ -372,11 +372,16 @@ class _Wave:
     layout: ArenaLayout
 
 
-def _plan_waves(items: Sequence[Tuple[str, int]], wave_elems: int) -> List[_Wave]:
-    """Pack keys (file order) into waves of at most `wave_elems` elements per model; a key larger than the window
-    gets a wave of its own (the reference likewise grows its buffer to the tensor, streaming.py:154-158)."""
-    waves, cur, cur_elems = [], [], 0
+def _plan_waves(items: Sequence[Tuple[str, int]], wave_elems: int) -> Tuple[List[_Wave], List[_Wave]]:
+    """(waves, split keys).  Keys (file order) are packed into waves of at most `wave_elems` elements per model.  A key
+    LARGER than that window (an embedding of a FLUX / LLM checkpoint under a small staging budget) becomes a wave of its
+    own that is moved through the window in pieces of whole rows of elements (SURVEY.md §8e "row-split"; the reference
+    instead grows its buffer to the tensor, streaming.py:154-158)."""
+    waves, cur, cur_elems, split = [], [], 0, []
     for key, n in items:
+        if n > wave_elems:
+            split.append(_Wave([key], plan_arena([(key, n)])))
+            continue
         if cur and cur_elems + n > wave_elems:
             waves.append(cur)
             cur, cur_elems = [], 0
@@ -384,7 +389,7 @@ def _plan_waves(items: Sequence[Tuple[str, int]], wave_elems: int) -> List[_Wave
         cur_elems += (n + 127) // 128 * 128
     if cur:
         waves.append(cur)
-    return [_Wave([k for k, _ in w], plan_arena(w)) for w in waves]
+    return [_Wave([k for k, _ in w], plan_arena(w)) for w in waves], split
 
 
 # host seconds per phase of the last fused merge() of this process (tools/bench_e2e.py prints it)
@@ -598,25 +603,30 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     in_esz, out_esz = DTYPE_REVERSE_MAPPING[in_dtype][1], DTYPE_REVERSE_MAPPING[output_dtype][1]
     # buffer sets (2 = double buffering), each holding n_models inputs + 1 output; the budget is shared between them
     n_sets = max(1, int(os.environ.get("MECHA_BUFFER_SETS", "2")))
-    per_set = max(total_buffer_size // n_sets, 1 << 20)
+    per_set = max(total_buffer_size // n_sets, 1 << 16)
     wave_elems = max(per_set // (n_models * in_esz + out_esz), 1024)
-    waves = _plan_waves(items, wave_elems)
-    if not waves:
+    waves, split_waves = _plan_waves(items, wave_elems)
+    if not waves and not split_waves:
         return
-    cap = max(w.layout.total_elems for w in waves)
+    # pieces of a split key: whole TIES tiles (4096 elements), as large as the window allows
+    piece_elems = max(wave_elems // 4096 * 4096, 4096)
+    cap_dev = max((w.layout.total_elems for w in waves), default=128)
+    cap = max(cap_dev, piece_elems if split_waves else 0)              # pinned staging: never more than the window
 
     def alloc_set():
         pin = dict(pin_memory=True) if is_cuda else {}
         return {
             "h_in": [torch.empty(cap, dtype=in_dtype, **pin) for _ in range(n_models)],
             "h_out": torch.empty(cap, dtype=output_dtype, **pin),
-            "h_flags_pinned": torch.empty(max(len(w.layout.keys) for w in waves), dtype=torch.int32, **pin),
-            "d_in": [torch.empty(cap, dtype=in_dtype, device=dev) for _ in range(n_models)],
-            "d_out": torch.empty(cap, dtype=output_dtype, device=dev),
+            "h_flags_pinned": torch.empty(max((len(w.layout.keys) for w in waves), default=1), dtype=torch.int32, **pin),
+            "d_in": [torch.empty(cap_dev, dtype=in_dtype, device=dev) for _ in range(n_models)],
+            "d_out": torch.empty(cap_dev, dtype=output_dtype, device=dev),
             "flags": None, "h_flags": None, "ev_h2d": None, "ev_comp": None, "ev_d2h": None, "wave": None,
         }
     with _phase("alloc"):
-        sets = [alloc_set() for _ in range(min(n_sets, len(waves)))]
+        sets = [alloc_set() for _ in range(min(n_sets, max(len(waves), 2 if split_waves else 1)))]
+    last_stats["pinned_bytes"] = max(last_stats.get("pinned_bytes", 0), len(sets) * cap * (n_models * in_esz + out_esz))
+    last_stats["split_keys"] = last_stats.get("split_keys", 0) + len(split_waves)
     s_copy_in = backend.stream() if is_cuda else None
     s_comp = backend.stream() if is_cuda else None
     s_copy_out = backend.stream() if is_cuda else None
@@ -745,9 +755,93 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             bs["write_fut"] = writer.submit(write)
         bs["wave"] = None
 
+    def run_split(wave: _Wave):
+        """A key larger than the staging window.  288 GB of HBM hold the whole key for every model, so only the TRANSFER is
+        split: its pieces go up through the pinned window (alternating the buffer sets: piece i + 1 is read from the files
+        while piece i crosses the link), the kernels run once over the whole key in HBM -- TIES thresholds are global per key
+        (ties.py:128-132), nothing about them changes --, and the result comes back through the window piece by piece into
+        the key's region of the file.  Every buffer set is idle when this runs."""
+        L = wave.layout
+        key, n = L.keys[0], L.numels[0]
+        meta = header[key]
+        big_in = [torch.empty(L.total_elems, dtype=in_dtype, device=dev) for _ in range(n_models)]
+        big_out = torch.empty(L.total_elems, dtype=output_dtype, device=dev)
+        pieces = [(s0, min(piece_elems, n - s0)) for s0 in range(0, n, piece_elems)]
+        events = []
+        for i, (s0, cnt) in enumerate(pieces):
+            bs = sets[i % len(sets)]
+            ev = bs.pop("ev_piece", None)
+            if ev is not None:
+                ev.synchronize()                                       # the copy that last read this set's staging buffers
+            with _phase("stage"):
+                fds = np.asarray([readers[id(m)].fileno() for m in plan.models], dtype=np.int32)
+                dst = np.asarray([bs["h_in"][mi].data_ptr() for mi in range(n_models)], dtype=np.uint64)
+                size = np.full(n_models, cnt * in_esz, dtype=np.uint64)
+                foff = np.asarray([readers[id(m)].file_offset(key) + s0 * in_esz for m in plan.models], dtype=np.int64)
+                _lib.check(hostlib.mecha_host_pread_many(fds.ctypes.data, dst.ctypes.data, size.ctypes.data, foff.ctypes.data,
+                                                         n_models, host_threads), "mecha_host_pread_many")
+            with (torch.cuda.stream(s_copy_in) if is_cuda else _null()):
+                for mi in range(n_models):
+                    big_in[mi][s0:s0 + cnt].copy_(bs["h_in"][mi][:cnt], non_blocking=True)
+                if is_cuda:
+                    bs["ev_piece"] = torch.cuda.Event()
+                    bs["ev_piece"].record(s_copy_in)
+                    events.append(bs["ev_piece"])
+        with (torch.cuda.stream(s_comp) if is_cuda else _null()):
+            if is_cuda:
+                for ev in events:
+                    s_comp.wait_event(ev)
+            for a in big_in:
+                a[n:].zero_()                                          # the arena's tail gap stays finite
+            segs_host, segs_dev = L.host_segments(), L.device_segments(dev)
+            flags = torch.zeros(1, dtype=torch.int32, device=dev)
+            nbytes = backend.workspace_bytes(plan, L)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if nbytes else None
+            skip = ()
+            if plan.kind == "lora":
+                entries, skip = lora_store.entries(L, header)
+                backend.run_lora(entries, big_in[0], big_out, flags)
+            else:
+                backend.run_fused(plan, big_in, big_out, L, segs_dev, segs_host, flags, ws)
+            fl = int(flags.cpu()[0])                                   # waits for the kernels
+        for bs in sets:
+            bs.pop("ev_piece", None)
+        if key in skip:
+            skipped.append(key)
+            return
+        if fl & _lib.FLAG_INPUT_NONFINITE:
+            if not _write_fallback(plan, readers, key, meta, sink, to_file, output_device, output_dtype):
+                skipped.append(key)
+            return
+        if (fl & _lib.FLAG_OUTPUT_NONFINITE) and check_finite_output:
+            log.warning("There are non finite values in key '%s': %s", key, meta)
+        discard = getattr(sink, "discard", False)
+        region = sink.reserve(key, meta) if to_file else None
+        whole = None if (to_file or discard) else torch.empty(n, dtype=output_dtype)
+        for i, (s0, cnt) in enumerate(pieces):
+            bs = sets[i % len(sets)]
+            wait_write(bs)                                             # this set's h_out may still be on its way to the file
+            with (torch.cuda.stream(s_copy_out) if is_cuda else _null()):
+                bs["h_out"][:cnt].copy_(big_out[s0:s0 + cnt], non_blocking=True)
+                if is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(s_copy_out)
+                    ev.synchronize()
+            if to_file:
+                def write(ptr=bs["h_out"].data_ptr(), off=region + s0 * out_esz, nb=cnt * out_esz):
+                    with _phase("write"):
+                        sink.write_at(off, ptr, nb, host_threads)
+                bs["write_fut"] = writer.submit(write)
+            elif not discard:
+                whole[s0:s0 + cnt].copy_(bs["h_out"][:cnt])
+        if whole is not None:
+            t = whole.view(meta.shape)
+            sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t
+
     # software pipeline over waves: stage(w+1) on the host overlaps H2D/compute/D2H of w
-    with _phase("stage"):
-        stage(sets[0], waves[0])
+    if waves:
+        with _phase("stage"):
+            stage(sets[0], waves[0])
     for w, wave in enumerate(waves):
         bs = sets[w % len(sets)]
         with _phase("launch"):
@@ -763,10 +857,15 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             drain(bs)
     for bs in sets:
         wait_write(bs)
+    for wave in split_waves:
+        with _phase("split_transfer"):
+            run_split(wave)
+    for bs in sets:
+        wait_write(bs)
     writer.shutdown()
     if is_cuda:
         torch.cuda.synchronize(dev)
-    last_stats["waves"] = last_stats.get("waves", 0) + len(waves)
+    last_stats["waves"] = last_stats.get("waves", 0) + len(waves) + len(split_waves)
 
 
 def _write_fallback(plan, readers, key, meta, sink, to_file, output_device, output_dtype) -> bool:

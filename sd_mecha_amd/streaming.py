@@ -260,6 +260,29 @@ class OutSafetensorsDict:
         for key, meta, off, n in zip(keys, metas, rel.tolist(), sizes.tolist()):
             self.entries[key] = {"dtype": DTYPE_REVERSE_MAPPING[meta.dtype][0], "shape": list(meta.shape), "data_offsets": [off, off + n]}
 
+    def reserve(self, key: str, meta: TensorMetadata) -> int:
+        """Claim the file region of one tensor that arrives in pieces (a key larger than the staging window, split by
+        rows): returns its offset inside the data section; fill it with write_at()."""
+        n = meta.nbytes()
+        with self._lock:
+            off = self._cursor
+            self._cursor += n
+        self.entries[key] = {"dtype": DTYPE_REVERSE_MAPPING[meta.dtype][0], "shape": list(meta.shape), "data_offsets": [off, off + n]}
+        return off
+
+    def write_at(self, rel_offset: int, src_ptr: int, nbytes: int, threads: int) -> None:
+        """`nbytes` from host memory at `src_ptr` into the data section at `rel_offset` (a piece of a reserved tensor)."""
+        if nbytes <= 0:
+            return
+        from . import _lib
+        self._join_prealloc()
+        srcs = np.asarray([src_ptr], dtype=np.uint64)
+        sizes = np.asarray([nbytes], dtype=np.uint64)
+        offs = np.asarray([self.data_start + rel_offset], dtype=np.int64)
+        args = (self._fd, srcs.ctypes.data, sizes.ctypes.data, offs.ctypes.data, 1, threads)
+        if not self._pages_reserved or _lib.lib().mecha_host_mmap_write_many(*args) != 0:
+            _lib.check(_lib.lib().mecha_host_pwrite_many(*args), "mecha_host_pwrite_many")
+
     def __setitem__(self, key: str, tensor: torch.Tensor) -> None:
         """WriteOnlyMapping protocol of the reference (typing_.py:12-20): tensor -> bytes -> file."""
         self.put(key, TensorMetadata(tensor.shape, tensor.dtype), tensor_bytes(tensor))

@@ -166,15 +166,20 @@ def test_product_backend_has_no_cpu_path(toy_models):
 
 
 # ------------------------------------------------------------------ scheduler end to end (oracle as test double)
-@pytest.mark.parametrize("buffer", [1 << 31, 1 << 16])        # one wave / many small waves (double buffering, a key > window)
+@pytest.mark.parametrize("buffer", [1 << 31, 1 << 18, 1 << 16])   # one wave / many small waves / keys larger than the window
 def test_scheduler_reproduces_reference_merge(toy_models, tmp_path, buffer):
     import safetensors.torch
     import sd_mecha_amd as amd
+    from sd_mecha_amd import merging
     from oracle_backend import OracleBackend
     be = OracleBackend()
     m = [amd.model(p) for p in toy_models]
     kw = dict(backend=be, output_dtype=torch.bfloat16, total_buffer_size=buffer)
     check_against_reference(amd.merge(amd.weighted_sum(m[0], m[1], alpha=0.5), **kw), "wsum")
+    if buffer == 1 << 16:
+        # 32 KiB per buffer set = 5461 elements per model: w.linear (12288) and w.conv (4608 -- fits) ... the large key moves
+        # through the window in row pieces, and the pinned staging stays inside the budget
+        assert merging.last_stats["split_keys"] >= 1 and merging.last_stats["pinned_bytes"] <= 2 * (1 << 16), merging.last_stats
     check_against_reference(amd.merge(amd.weighted_sum(m[0], m[1], alpha=0.3), **{**kw, "output_dtype": torch.float16}), "wsum_f16")
     check_against_reference(amd.merge(amd.n_average(m[0], m[1], m[2]), **kw), "navg3")
     check_against_reference(amd.merge(amd.n_average(*m), **kw), "navg4")             # m3's bias is non-finite: key skipped
