@@ -14,6 +14,7 @@ from .recipe_nodes import (  # noqa: F401
     RealizedKeyRelation,
     Return,
     StateDict,
+    deserialize,
     LiteralRecipeNode,
     MergeMethod,
     MergeRecipeNode,

@@ -446,6 +446,7 @@ def merge(
     if not omit_non_finite_inputs:
         raise NotImplementedError("omit_non_finite_inputs=False is not supported: the finite check is fused into the kernels")
     recipe = value_to_node(recipe)
+    original_recipe = recipe                                                 # what the output's metadata records (merging.py:152, :200)
     if fallback_model is not None:
         recipe = recipe | value_to_node(fallback_model)                      # merging.py:154-155
     backend = backend or HipBackend(merge_device)
@@ -457,7 +458,6 @@ def merge(
     readers = {id(m): InSafetensorsDict(m.path) for m in models}
     try:
         plan = fuse(recipe)
-        recipe_text = serialize(recipe)
         # LoRA files name their tensors after the base keys (lora_<stem>.lora_up.weight ...): they take no part in config inference
         aux = _lora_file_nodes(recipe)
         merge_inputs = [m for m in models if id(m) not in aux]
@@ -472,6 +472,11 @@ def merge(
         # the keys the recipe can produce (graph_finalization.py:113-141, structural form: GraphInfo), in the config's order
         # (merging.py:202) or the order the inputs hold them.  A key some input lacks is still produced when a `|` further
         # up has a default for it (logistics.py:15-19).
+        try:                                                                # merging.py:259-263
+            recipe_text = serialize(original_recipe, {id(m): (config.identifier if config is not None else "structural") for m in merge_inputs})
+        except TypeError:
+            log.warning("The recipe graph could not be serialized. The output state dict will not contain the recipe.")
+            recipe_text = None
         info = GraphInfo(recipe, readers)
         root_keys = info.keys(recipe)
         if root_keys is None:
@@ -511,7 +516,8 @@ def merge(
                 sink = OutSafetensorsDict(out_path, header, recipe_text)
         else:
             sink = output if output is not None else {}
-            sink["__metadata__"] = {"mecha_recipe": recipe_text}              # merging.py:287-288
+            if recipe_text is not None:
+                sink["__metadata__"] = {"mecha_recipe": recipe_text}          # merging.py:287-288
 
         # Keys the batched kernels cover go through the fused pipeline, one run per storage dtype the inputs hold them in
         # (a checkpoint may keep, say, its VAE in fp32 beside a bf16 UNet); everything else -- integer keys (position_ids: the

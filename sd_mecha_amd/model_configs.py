@@ -79,48 +79,104 @@ def get_all() -> List[ModelConfig]:
     return [resolve(i) for i in shapes.available()]
 
 
+# ------------------------------------------------------------------ detection by key-name overlap
+class _NameIndex:
+    """Every name a shipped config knows a tensor by (its key, or one of the key's aliases) -> the configs that know it.
+    Built once; a state dict is then matched against ALL configs in one pass over its keys (the reference walks the
+    configs one by one and resolves every key for each, graph_finalization.py:1024-1058)."""
+
+    def __init__(self, configs: Sequence[ModelConfig]):
+        self.configs = list(configs)
+        self.by_name: Dict[str, List[Tuple[int, str, bool]]] = {}          # name -> [(config index, canonical key, mandatory)]
+        self.n_keys = [len(c.keys()) for c in self.configs]
+        self.n_mandatory = [0] * len(self.configs)
+        for ci, cfg in enumerate(self.configs):
+            for key, meta in cfg.keys().items():
+                mandatory = not meta.optional
+                self.n_mandatory[ci] += mandatory
+                for name in (key, *meta.aliases):
+                    self.by_name.setdefault(name, []).append((ci, key, mandatory))
+
+
+_index: Optional[_NameIndex] = None
+
+
+def _name_index() -> _NameIndex:
+    global _index
+    if _index is None:
+        _index = _NameIndex(get_all())
+    return _index
+
+
 @dataclasses.dataclass
 class ConfigMatchStats:
-    """graph_finalization.py:993-1013."""
+    """How well one config explains the state dicts seen so far (graph_finalization.py:993-1013): the config keys they all
+    hold, and -- averaged over the state dicts -- the share of a state dict's keys the config does not know and the share
+    of the config's keys that are mandatory and absent.  Kept as sums over `count` state dicts."""
     intersection: Set[str]
-    state_dict_misses: float = 0.0      # share of the state dict's keys the config does not know
-    config_misses: float = 0.0          # share of the config's mandatory keys the state dict lacks
+    unknown_share_sum: float = 0.0
+    absent_share_sum: float = 0.0
     count: int = 0
 
+    @property
+    def state_dict_misses(self) -> float:
+        return self.unknown_share_sum / self.count if self.count else 0.0
+
+    @property
+    def config_misses(self) -> float:
+        return self.absent_share_sum / self.count if self.count else 0.0
+
     def __or__(self, other: "ConfigMatchStats") -> "ConfigMatchStats":
-        new_count = self.count + other.count
-        common = self.intersection & other.intersection
-        if new_count == 0:
-            return ConfigMatchStats(common, 0.0, 0.0, new_count)
-        sw, ow = self.count / new_count, other.count / new_count
-        return ConfigMatchStats(common, self.state_dict_misses * sw + other.state_dict_misses * ow,
-                                self.config_misses * sw + other.config_misses * ow, new_count)
+        return ConfigMatchStats(self.intersection & other.intersection, self.unknown_share_sum + other.unknown_share_sum,
+                                self.absent_share_sum + other.absent_share_sum, self.count + other.count)
 
 
-def create_config_stats(config: ModelConfig, dict_keys: Optional[Set[str]] = None) -> ConfigMatchStats:
-    """graph_finalization.py:1042-1058."""
-    config_keys = set(config.keys())
-    if not dict_keys:
-        return ConfigMatchStats(config_keys)
-    n = len(dict_keys)
-    resolved = {config.resolve_alias(k) for k in dict_keys}
-    matched = resolved & config_keys
-    extra = resolved - config_keys
-    missing = sum(1 for k, m in config.keys().items() if k not in resolved and not m.optional)
-    return ConfigMatchStats(matched, len(extra) / n, missing / len(config.keys()), 1)
+def _match(names: Iterable[str], only: Optional[int] = None) -> Tuple[int, List[Optional[ConfigMatchStats]]]:
+    """One pass over a state dict's key names: per config, the canonical keys they resolve to, how many of the names the
+    config knows at all, how many mandatory keys they cover.  `only`: restrict to one config index."""
+    idx = _name_index()
+    n_cfg = len(idx.configs)
+    hit: List[Set[str]] = [set() for _ in range(n_cfg)]
+    known = [0] * n_cfg
+    mandatory_hit = [0] * n_cfg
+    total = 0
+    for name in names:
+        total += 1
+        for ci, key, mandatory in idx.by_name.get(name, ()):
+            known[ci] += 1
+            if key not in hit[ci]:
+                hit[ci].add(key)
+                mandatory_hit[ci] += mandatory
+    out: List[Optional[ConfigMatchStats]] = [None] * n_cfg
+    for ci in range(n_cfg):
+        if only is not None and ci != only:
+            continue
+        unknown = (total - known[ci]) / total if total else 0.0
+        absent = (idx.n_mandatory[ci] - mandatory_hit[ci]) / idx.n_keys[ci] if idx.n_keys[ci] else 0.0
+        out[ci] = ConfigMatchStats(hit[ci], unknown, absent, 1)
+    return total, out
+
+
+def create_config_stats(config: ModelConfig, dict_keys: Optional[Iterable[str]] = None) -> ConfigMatchStats:
+    """The statistics of one given config for one state dict (graph_finalization.py:1042-1058); without a state dict, the
+    config's own keys and no observation."""
+    names = set(dict_keys) if dict_keys is not None else set()
+    if not names:
+        return ConfigMatchStats(set(config.keys()))
+    idx = _name_index()
+    ci = next(i for i, c in enumerate(idx.configs) if c.identifier == config.identifier)
+    return _match(names, only=ci)[1][ci]
 
 
 def generate_configs_stats(state_dict_keys: Iterable[str]) -> Dict[str, ConfigMatchStats]:
-    """graph_finalization.py:1024-1039: the configs that match at least 10 % of the state dict's keys."""
-    keys = set(state_dict_keys)
-    if not keys:
+    """The candidate configs of a state dict: those whose keys cover at least 10 % of its key names
+    (graph_finalization.py:1024-1039, the 10 % rule at :1036)."""
+    names = set(state_dict_keys)
+    if not names:
         return {}
-    out = {}
-    for config in get_all():
-        stats = create_config_stats(config, keys)
-        if len(stats.intersection) >= len(keys) * 0.1:
-            out[config.identifier] = stats
-    return out
+    total, stats = _match(names)
+    idx = _name_index()
+    return {cfg.identifier: st for cfg, st in zip(idx.configs, stats) if st is not None and len(st.intersection) >= total * 0.1}
 
 
 def infer(key_sets: Sequence[Iterable[str]], hints: Sequence[Optional[str]] = ()) -> Optional[ModelConfig]:

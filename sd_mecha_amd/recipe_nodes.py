@@ -141,6 +141,9 @@ class RealizedKeyRelation:
         return f"RealizedKeyRelation(outputs={self.outputs}, inputs={dict(self.inputs)}, meta={self.meta})"
 
 
+_IMPLEMENTATION_KEYWORDS = frozenset({"key", "cache", "out_dtype", "flags", "check_finite", "return_thresholds", "return_sweeps", "keep_bits"})
+
+
 def _interface_of(annotation):
     if isinstance(annotation, type) and issubclass(annotation, ParameterType):
         return annotation.interface
@@ -165,6 +168,12 @@ class MergeMethod:
             sig = sig.replace(parameters=list(sig.parameters.values())[1:])          # drop self (merge_methods.py:214-217)
         self.signature = sig
         self.accepts_kwargs = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())
+        # The signature recipes are built and serialized with = the reference method's parameters.  This package's own
+        # shims also carry implementation keywords (output dtype, flag words, ...) that are no part of a recipe.
+        annotated = any(isinstance(p.annotation, type) and issubclass(p.annotation, ParameterType) for p in sig.parameters.values())
+        self.public_signature = sig.replace(parameters=[
+            p for p in sig.parameters.values()
+            if p.kind != p.VAR_KEYWORD and (annotated or not (p.kind == p.KEYWORD_ONLY and p.name in _IMPLEMENTATION_KEYWORDS))])
         for reserved in ("key", "key_relation", "cache", "output_reused"):             # merge_methods.py:262-264
             p = sig.parameters.get(reserved)
             if p is not None and p.annotation is not p.empty and _interface_of(p.annotation) is not p.annotation:
@@ -187,7 +196,11 @@ class MergeMethod:
 
     def __call__(self, *args, **kwargs):
         if any(isinstance(a, RecipeNode) for a in args) or any(isinstance(a, RecipeNode) for a in kwargs.values()):
-            return MergeRecipeNode(self, tuple(value_to_node(a) for a in args), {k: value_to_node(v) for k, v in kwargs.items()})
+            # merge_methods.py:339-358: bind to the signature and apply the defaults, so that a recipe (and its .mecha text)
+            # names every hyper-parameter; positional-or-keyword parameters travel as args, keyword-only ones as kwargs
+            bound = self.public_signature.bind(*args, **kwargs)
+            bound.apply_defaults()
+            return MergeRecipeNode(self, tuple(value_to_node(a) for a in bound.args), {k: value_to_node(v) for k, v in bound.kwargs.items()})
         if self.wrapped_is_class:
             return self.__wrapped__()(*args, **kwargs)
         return self.__wrapped__(*args, **kwargs)
@@ -203,7 +216,7 @@ class MergeMethod:
     def param_names(self, n_args: int) -> List[str]:
         """Parameter name of each positional argument (a ``*varargs`` parameter repeats)."""
         names, var = [], None
-        for p in self.signature.parameters.values():
+        for p in self.public_signature.parameters.values():
             if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD):
                 names.append(p.name)
             elif p.kind == p.VAR_POSITIONAL:
@@ -267,47 +280,154 @@ def get_all() -> List[MergeMethod]:
     return list(_registry.values())
 
 
-# ------------------------------------------------------------------ .mecha text (serialization.py:143-238)
+# ------------------------------------------------------------------ .mecha text (serialization.py:26-238)
 MECHA_FORMAT_VERSION = "0.1.0"
+_CONSTANTS = {"null": None, "true": True, "false": False}
 
 
-def serialize(recipe: RecipeNode) -> str:
+def serialize(recipe: RecipeNode, model_configs: Optional[Mapping[int, str]] = None) -> str:
+    """The reference's `.mecha` text (serialization.py:143-238, SerializerVisitor :184-238), line for line: python scalars as
+    the three lines the reference's graph gives them (``dict key=V`` / ``literal &d model_config="singleton-mecha"
+    merge_space="param"`` / ``merge "convert_singleton" &l``, merge_methods.py:905-919), models with the config the merge
+    solved for them (``model_configs``: {id(node): identifier}; default: the node's own config or ``"structural"``), merge
+    lines with positional and keyword arguments as bound by the method's signature, defaults included.  Equal lines are
+    emitted once and referenced by ``&n`` (:233-238)."""
     instructions: List[str] = []
 
     def add(line: str) -> str:
-        if line in instructions:
+        try:
             return f"&{instructions.index(line)}"
-        instructions.append(line)
-        return f"&{len(instructions) - 1}"
+        except ValueError:
+            instructions.append(line)
+            return f"&{len(instructions) - 1}"
 
     def value(v) -> str:
         if isinstance(v, str):
             return '"' + v.replace("\\", "\\\\").replace('"', '\\"') + '"'
-        if isinstance(v, bool):
-            return "true" if v else "false"
-        if v is None:
-            return "null"
-        if isinstance(v, (int, float)):
-            return str(v)
-        if isinstance(v, dict):
+        if isinstance(v, Mapping):
             return add("dict " + " ".join(f"{k}={value(x)}" for k, x in v.items()))
+        if isinstance(v, (int, float)) and not isinstance(v, bool):
+            return str(v)
+        if v is None or isinstance(v, bool):
+            return {None: "null", True: "true", False: "false"}[v]
         if isinstance(v, RecipeNode):
             return node(v)
         raise TypeError(f"type {type(v)} cannot be serialized: {v}")
 
-    done: Dict[int, str] = {}                   # recipes are DAGs (`x | x`-style sharing): each node is visited once
+    done: Dict[int, str] = {}                   # recipes are DAGs: each node is visited once
 
     def node(n: RecipeNode) -> str:
-        if isinstance(n, ModelRecipeNode):
-            return add(f"model {value(str(n.path))} model_config=null merge_space=\"weight\"")
-        if isinstance(n, LiteralRecipeNode):
-            return value(n.value)
-        if isinstance(n, MergeRecipeNode):
-            if id(n) not in done:
-                parts = ["merge", value(n.merge_method.identifier)] + [value(a) for a in n.args] + [f"{k}={value(v)}" for k, v in n.kwargs.items()]
-                done[id(n)] = add(" ".join(parts))
+        if id(n) in done:
             return done[id(n)]
-        raise TypeError(type(n))
+        if isinstance(n, ModelRecipeNode):
+            config = (model_configs or {}).get(id(n)) or n.config or "structural"
+            ref = add(f"model {value(str(n.path))} model_config={value(config)} merge_space=\"weight\"")
+        elif isinstance(n, LiteralRecipeNode):
+            if isinstance(n.value, Mapping):
+                ref = value(n.value)
+            else:                               # a scalar hyper-parameter: singleton dict -> literal -> convert_singleton
+                lit = add(f"literal {value({'key': n.value})} model_config=\"singleton-mecha\" merge_space=\"param\"")
+                ref = add(f"merge \"convert_singleton\" {lit}")
+        elif isinstance(n, MergeRecipeNode):
+            parts = ["merge", value(n.merge_method.identifier)] + [value(a) for a in n.args] + [f"{k}={value(v)}" for k, v in n.kwargs.items()]
+            ref = add(" ".join(parts))
+        else:
+            raise TypeError(type(n))
+        done[id(n)] = ref
+        return ref
 
     node(recipe)
     return "\n".join([f"version {MECHA_FORMAT_VERSION}"] + instructions)
+
+
+def _tokenize(line: str) -> List[str]:
+    """serialization.py:100-132: split at blanks outside quotes; a quoted string keeps its quotes (and a ``name=`` prefix)."""
+    tokens, cur, prefix, inside, escape = [], [], [], False, False
+    for ch in line:
+        if escape:
+            escape = False
+        elif ch == "\\":
+            escape = True
+            continue
+        elif ch == '"':
+            inside = not inside
+            if inside:
+                prefix, cur = cur, []
+            else:
+                tokens.append("".join(prefix) + '"' + "".join(cur) + '"')
+                cur, prefix = [], []
+            continue
+        elif ch == " " and not inside:
+            if cur:
+                tokens.append("".join(cur))
+                cur = []
+            continue
+        cur.append(ch)
+    if inside:
+        raise ValueError("mismatched quotes in input")
+    if cur:
+        tokens.append("".join(cur))
+    return tokens
+
+
+def deserialize(recipe) -> RecipeNode:
+    """Recreate a recipe graph from `.mecha` text (serialization.py:26-140): ``dict`` / ``literal`` / ``model`` / ``merge``
+    lines, ``&n`` back references, ``#`` comments.  Methods are looked up by identifier in this package's registry;
+    ``convert_singleton`` of a literal ``{"key": v}`` is the scalar ``v``."""
+    lines = recipe.split("\n") if not isinstance(recipe, list) else recipe
+    if not lines or not lines[0].startswith("version"):
+        raise RuntimeError("bad format: expected version at line 1")
+    if lines[0] != f"version {MECHA_FORMAT_VERSION}":
+        raise RuntimeError(f"bad recipe version: got {lines[0]}, expected version {MECHA_FORMAT_VERSION}")
+    results: List[Any] = []
+
+    def arg_value(arg: str, index: int):
+        try:
+            if arg in _CONSTANTS:
+                return _CONSTANTS[arg]
+            if arg.startswith("&"):
+                ref = int(arg[1:])
+                if ref < 0 or ref >= len(results):
+                    raise ValueError(f"reference {arg} out of bounds")
+                return results[ref]
+            if arg.startswith('"') and arg.endswith('"'):
+                return arg[1:-1]
+            if "." in arg or "e" in arg.lower():
+                return float(arg)
+            return int(arg)
+        except ValueError as e:
+            raise ValueError(f"argument {index}: {e}")
+
+    for line_num, line in enumerate(lines[1:], 2):
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        try:
+            command, *args = _tokenize(line)
+            positional, named = [], {}
+            for i, arg in enumerate(args):
+                if "=" in arg and not arg.startswith('"'):
+                    k, v = arg.split("=", 1)
+                    named[k] = arg_value(v, i)
+                else:
+                    positional.append(arg_value(arg, i))
+            if command == "dict":
+                results.append(dict(*positional, **named))
+            elif command == "literal":
+                results.append(LiteralRecipeNode(positional[0]))
+            elif command == "model":
+                config = named.get("model_config")
+                results.append(ModelRecipeNode(pathlib.Path(positional[0]), None if config in (None, "structural") else config))
+            elif command == "merge":
+                method, *positional = positional
+                if method == "convert_singleton":
+                    lit = positional[0]
+                    inner = lit.value if isinstance(lit, LiteralRecipeNode) else lit
+                    results.append(LiteralRecipeNode(inner["key"]) if isinstance(inner, Mapping) and "key" in inner else value_to_node(inner))
+                else:
+                    results.append(resolve(method)(*positional, **named))
+            else:
+                raise ValueError(f"unknown command: {command}")
+        except ValueError as e:
+            raise ValueError(f"line {line_num}: {e}.\n    {line}")
+    return results[-1]

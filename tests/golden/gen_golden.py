@@ -363,6 +363,87 @@ def json_dumps(x):
     return json.dumps(x)
 
 
+def gen_mecha_text(_out):
+    """The `.mecha` text the reference embeds in its outputs (serialization.py:184-238 through merging.py:260, :287-288) for
+    the benchmark recipes, as a JSON fixture {name: text}; the directory of the model files is replaced by <DIR>."""
+    import json
+    import safetensors.torch
+    from tqdm import tqdm
+
+    class quiet(tqdm):
+        def __init__(self, *a, **k):
+            k["disable"] = True
+            super().__init__(*a, **k)
+
+    g = torch.Generator().manual_seed(5)
+    texts = {}
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        shapes = {"w.linear": (12, 8), "w.bias": (12,)}
+        for m in range(3):
+            safetensors.torch.save_file({k: torch.randn(s, generator=g).to(torch.bfloat16) for k, s in shapes.items()}, str(td / f"m{m}.safetensors"))
+        kshapes = {"unet.out.2.weight": (4, 320, 3, 3), "unet.out.2.bias": (4,)}
+        for name in ("ka", "kb"):
+            safetensors.torch.save_file({k: torch.randn(s, generator=g).to(torch.bfloat16) for k, s in kshapes.items()}, str(td / f"{name}.safetensors"))
+        ms = [sd_mecha.model(td / f"m{m}.safetensors") for m in range(3)]
+        ka, kb = (sd_mecha.model(td / f"{n}.safetensors", config="sdxl-kohya") for n in ("ka", "kb"))
+        kw = dict(threads=0, output_dtype=torch.bfloat16, tqdm=quiet)
+        d = [linear.subtract(m, ms[0]) for m in ms[1:]]
+        recipes = {
+            "wsum": (linear.weighted_sum(ms[0], ms[1], alpha=0.5), {}),
+            "wsum_default": (linear.weighted_sum(ms[0], ms[1]), {}),
+            "navg": (linear.n_average(*ms), {}),
+            "ties": (linear.add_difference(ms[0], ties.ties_sum(*d, k=0.2), alpha=1.0) | ms[0], {}),
+            "ties_vote_fallback_model": (linear.add_difference(ms[0], ties.ties_sum(*d, k=0.2, vote_sgn=True), alpha=0.7), {"fallback_model": ms[0]}),
+            "rotate": (svd.rotate(ms[0], ms[1], alignment=1.0, alpha=0.0), {}),
+            "operators": (ms[0] + (ms[1] - ms[0]) * 0.5, {}),
+            "slerp": (linear.slerp(ms[0], ms[1], alpha=0.3), {}),
+            "known_config": (linear.weighted_sum(ka, kb, alpha=0.25), {}),
+        }
+        for name, (r, extra) in recipes.items():
+            res = sd_mecha.merge(r, **kw, **extra)
+            texts[name] = res["__metadata__"]["mecha_recipe"].replace(str(td), "<DIR>")
+    (HERE / "mecha_text.json").write_text(json.dumps(texts, indent=1))
+    print("mecha_text", len(texts), "recipes")
+
+
+def gen_e2e_alias(out):
+    """Row (f)2 through the real sd_mecha.merge: two FLUX-like files with tiny tensors under REAL key names -- one under the
+    config's canonical names, one under the alias names a diffuser-only file uses, both with a key the config does not know --:
+    the config is detected from the names (graph_finalization.py:1024-1058), the alias-named tensors are read
+    (merging.py:394-403) and the output carries canonical names."""
+    import safetensors.torch
+    from tqdm import tqdm
+    from sd_mecha.extensions import model_configs
+
+    class quiet(tqdm):
+        def __init__(self, *a, **k):
+            k["disable"] = True
+            super().__init__(*a, **k)
+
+    cfg = model_configs.resolve("flux-flux")
+    canon = list(cfg.components()["diffuser"].keys())[:60]
+    aliases = [cfg.keys()[k].aliases[0] for k in canon]
+    rng = np.random.default_rng(33)
+    a = {k: rand_half(rng, (8, 16), "bfloat16") for k in canon}
+    b = {al: rand_half(rng, (8, 16), "bfloat16") for al in aliases}
+    a["junk.weight"] = torch.ones(3, dtype=torch.bfloat16)
+    b["junk.weight"] = torch.zeros(3, dtype=torch.bfloat16)
+    out["canon"], out["aliases"] = np.array(canon), np.array(aliases)
+    out["a"] = np.stack([bits(a[k]) for k in canon])
+    out["b"] = np.stack([bits(b[al]) for al in aliases])
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        safetensors.torch.save_file(a, str(td / "a.safetensors"))
+        safetensors.torch.save_file(b, str(td / "b.safetensors"))
+        res = sd_mecha.merge(linear.weighted_sum(sd_mecha.model(td / "a.safetensors"), sd_mecha.model(td / "b.safetensors"), alpha=0.3),
+                             threads=0, output_dtype=torch.bfloat16, tqdm=quiet, check_extra_keys=False)
+    text = res.pop("__metadata__")["mecha_recipe"]
+    out["config_line"] = np.array([ln for ln in text.splitlines() if ln.startswith("model ")][0].split("model_config=")[1].split(" ")[0])
+    out["out_keys"] = np.array(sorted(res))
+    out["out"] = np.stack([bits(res[k]) for k in canon])
+
+
 def gen_e2e_lora(out):
     """sd_mecha.convert(model(lora_file), base) + add_difference through sd_mecha.merge (lycoris.py:52-85) on a
     toy checkpoint with REAL sdxl-kohya key names and shapes (LycorisToBase takes the target shape from the config).
@@ -468,12 +549,14 @@ def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
     only = set(sys.argv[1:])
     for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare),
-                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_mixed", gen_e2e_mixed), ("e2e_lora", gen_e2e_lora),
+                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_mixed", gen_e2e_mixed), ("e2e_alias", gen_e2e_alias), ("e2e_lora", gen_e2e_lora), ("mecha_text", gen_mecha_text),
                      ("configs", gen_configs)]:
         if only and name not in only:
             continue
         out = {}
         fn(out)
+        if not out:
+            continue
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(name, len(out), "arrays", (HERE / f"{name}.npz").stat().st_size, "bytes")
 

@@ -89,7 +89,14 @@ def _bodies():
             return models[0]
         return _t(O.ties_sum([_np(m).reshape(-1) for m in models], k=float(k), vote_sgn=bool(vote_sgn)), models[0])
 
-    return {"weighted_sum": weighted_sum, "n_average": n_average, "add_difference": add_difference, "subtract": subtract,
+    def scale(a, alpha=1.0, *, key=None, **_):
+        al = _scalar(alpha)
+        if math.isclose(al, 0.0):
+            return 0.0
+        a = _resolve(a, key)
+        return _t(O.scale(_np(a).reshape(-1), al), a)
+
+    return {"scale": scale, "weighted_sum": weighted_sum, "n_average": n_average, "add_difference": add_difference, "subtract": subtract,
             "ties_sum": ties_sum}
 
 

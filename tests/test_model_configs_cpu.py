@@ -79,3 +79,46 @@ def test_merge_detects_config_and_resolves_aliases(tmp_path):
     out = amd.merge(amd.weighted_sum(amd.model(tmp_path / "c.safetensors"), amd.model(tmp_path / "c.safetensors"), alpha=0.5),
                     backend=OracleBackend(), output_dtype=torch.float32)
     assert {k for k in out if k != "__metadata__"} == set(c)
+
+
+def _alias_case(tmp_path):
+    import safetensors.torch
+    g = load_golden("e2e_alias")
+    canon, aliases = [str(k) for k in g["canon"]], [str(k) for k in g["aliases"]]
+
+    def bf16(bits):
+        return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16).copy()).view(torch.bfloat16).reshape(8, 16)
+    a = {k: bf16(x) for k, x in zip(canon, g["a"])}
+    b = {k: bf16(x) for k, x in zip(aliases, g["b"])}
+    a["junk.weight"] = torch.ones(3, dtype=torch.bfloat16)
+    b["junk.weight"] = torch.zeros(3, dtype=torch.bfloat16)
+    safetensors.torch.save_file(a, str(tmp_path / "a.safetensors"))
+    safetensors.torch.save_file(b, str(tmp_path / "b.safetensors"))
+    return g, canon
+
+
+def check_alias_merge(tmp_path, **kw):
+    """The reference's own output for an alias-named FLUX-like pair (tests/golden/e2e_alias.npz): detected config, canonical
+    output names, bit-identical tensors, and the config named in the embedded recipe."""
+    import sd_mecha_amd as amd
+    g, canon = _alias_case(tmp_path)
+    out = amd.merge(amd.weighted_sum(amd.model(tmp_path / "a.safetensors"), amd.model(tmp_path / "b.safetensors"), alpha=0.3),
+                    output_dtype=torch.bfloat16, **kw)
+    text = out.pop("__metadata__")["mecha_recipe"]
+    assert f"model_config={str(g['config_line'])} " in text
+    assert sorted(out) == [str(k) for k in g["out_keys"]]
+    for k, want in zip(canon, g["out"]):
+        assert np.array_equal(out[k].cpu().contiguous().view(torch.int16).numpy().view(np.uint16).reshape(-1), want.reshape(-1)), k
+
+
+def test_alias_merge_matches_reference_cpu(tmp_path):
+    from oracle_backend import OracleBackend
+    check_alias_merge(tmp_path, backend=OracleBackend())
+
+
+@pytest.mark.gpu
+def test_alias_merge_matches_reference_gpu(tmp_path):
+    """Row (f)2 on the HIP path: an alias-named, auto-detected checkpoint pair through the fused batched kernels."""
+    from sd_mecha_amd import merging
+    check_alias_merge(tmp_path, merge_device="cuda")
+    assert merging.last_stats["fused_keys"] == 60 and merging.last_stats["generic_keys"] == 0

@@ -155,6 +155,62 @@ def test_fuser_recognises_the_benchmark_recipes(toy_models):
     assert text.splitlines()[0] == "version 0.1.0" and 'merge "ties_sum"' in text and 'merge "add_difference" &0' in text
 
 
+# ------------------------------------------------------------------ .mecha text (row f1)
+def _mecha_recipes(amd, d):
+    ms = [amd.model(d / f"m{i}.safetensors") for i in range(3)]
+    ka, kb = (amd.model(d / f"{n}.safetensors", config="sdxl-kohya") for n in ("ka", "kb"))
+    dl = [amd.subtract(m, ms[0]) for m in ms[1:]]
+    return {
+        "wsum": (amd.weighted_sum(ms[0], ms[1], alpha=0.5), {}),
+        "wsum_default": (amd.weighted_sum(ms[0], ms[1]), {}),
+        "navg": (amd.n_average(*ms), {}),
+        "ties": (amd.add_difference(ms[0], amd.ties_sum(*dl, k=0.2), alpha=1.0) | ms[0], {}),
+        "ties_vote_fallback_model": (amd.add_difference(ms[0], amd.ties_sum(*dl, k=0.2, vote_sgn=True), alpha=0.7), {"fallback_model": ms[0]}),
+        "rotate": (amd.rotate(ms[0], ms[1], alignment=1.0, alpha=0.0), {}),
+        "operators": (ms[0] + (ms[1] - ms[0]) * 0.5, {}),
+        "slerp": (amd.slerp(ms[0], ms[1], alpha=0.3), {}),
+        "known_config": (amd.weighted_sum(ka, kb, alpha=0.25), {}),
+    }
+
+
+def test_mecha_text_equals_the_references(tmp_path):
+    """serialization.py:184-238: the recipe text this backend embeds in its outputs is, byte for byte, the text the reference
+    embeds for the same recipe (tests/golden/mecha_text.json, from the real sd_mecha.merge); deserialize (:26-140) reads it
+    back into a graph that serializes to the same text and fuses the same way."""
+    import safetensors.torch
+    import sd_mecha_amd as amd
+    from sd_mecha_amd.merging import fuse
+    from oracle_backend import OracleBackend
+    want = json.loads((pathlib.Path(__file__).resolve().parent / "golden" / "mecha_text.json").read_text())
+    g = torch.Generator().manual_seed(5)
+    for i in range(3):
+        safetensors.torch.save_file({"w.linear": torch.randn(12, 8, generator=g).to(torch.bfloat16), "w.bias": torch.randn(12, generator=g).to(torch.bfloat16)},
+                                    str(tmp_path / f"m{i}.safetensors"))
+    for n in ("ka", "kb"):
+        safetensors.torch.save_file({"unet.out.2.weight": torch.randn(4, 320, 3, 3, generator=g).to(torch.bfloat16),
+                                     "unet.out.2.bias": torch.randn(4, generator=g).to(torch.bfloat16)}, str(tmp_path / f"{n}.safetensors"))
+    recipes = _mecha_recipes(amd, tmp_path)
+    assert sorted(recipes) == sorted(want)
+    be = OracleBackend()
+    for name, (recipe, extra) in recipes.items():
+        expect = want[name].replace("<DIR>", str(tmp_path))
+        if name not in ("rotate", "slerp"):                                  # the CPU double has no body for these two: text only
+            res = amd.merge(recipe, backend=be, output_dtype=torch.bfloat16, threads=0, **extra)
+            assert res["__metadata__"]["mecha_recipe"] == expect, name
+        config = {"known_config": "sdxl-kohya"}.get(name)
+        text = amd.serialize(recipe)
+        assert text == expect, name                                          # standalone: the node's own config or "structural"
+        again = amd.deserialize(expect)
+        assert amd.serialize(again) == expect, name
+        a, b = fuse(recipe), fuse(again)
+        assert (a is None) == (b is None) and (a is None or (a.kind, a.params) == (b.kind, b.params)), name
+        assert config is None or all(m.config == config for m in __import__("sd_mecha_amd").merging.collect_models(again))
+    with pytest.raises(RuntimeError, match="bad recipe version"):
+        amd.deserialize("version 9.9.9\nmodel \"x.safetensors\"")
+    with pytest.raises(ValueError, match="line 2"):
+        amd.deserialize("version 0.1.0\nfrobnicate 1 2")
+
+
 def test_product_backend_has_no_cpu_path(toy_models):
     import sd_mecha_amd as amd
     m = [amd.model(p) for p in toy_models]
