@@ -191,6 +191,20 @@ int mecha_ties_sum_extended(const void *const *deltas, int n_models, const uint3
                             float *thresholds_out, void *workspace, size_t workspace_bytes,
                             uint32_t *flags, void *stream);
 
+/* model_stock (ties.py:137-159): out = nan_to_num(t * (sum(deltas) / n)) with the Model-Stock factor t of ties.py:146-159 per slice
+ * of the key's last dimension (`row_len` elements): t = n c / (1 + (n - 1) c), c = mean cosine of consecutive deltas
+ * (CosineSimilarity(dim=-1, eps=cos_eps)).  nan_to_num with torch's defaults: nan -> 0, +-inf -> +-FLT_MAX.  2..8 deltas. */
+size_t mecha_model_stock_workspace_bytes(int n_models, int64_t numel, int64_t row_len);
+int mecha_model_stock(const void *const *deltas, int n_models, void *out, int64_t numel, int64_t row_len, int in_dtype,
+                      int out_dtype, float cos_eps, void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream);
+
+/* dropout, "n-supermario" (ties.py:202-238) at odd whole `overlap` (its default): delta m keeps the elements whose bit is set in
+ * ITS mask (`keep_bits`: device uint32[n_models][ceil(numel/32)], drawn by the host shim with numpy's default_rng(seed).binomial
+ * exactly as the reference draws them, :214-217);  out = sum_m masked delta_m / max(number of masks set, 1) / rescalar,
+ * rescalar = (1 - probability) ** rescale (the shim applies :231-235). */
+int mecha_dropout(const void *const *deltas, int n_models, const uint32_t *keep_bits, void *out, int64_t numel, int in_dtype,
+                  int out_dtype, float rescalar, uint32_t *flags, void *stream);
+
 /* HOST function: the Bernoulli keep masks the reference draws on CPU (ties.py:29-33, :63-64):
  * torch.Generator().manual_seed(seed), then torch.bernoulli(1 - probability) per delta in order
  * (MT19937, one 24-bit uniform per element).  Writes bit-packed masks, layout as `keep_bits`

@@ -329,6 +329,43 @@ def ties_sum_with_dropout(deltas: Sequence[np.ndarray], probability: float = 0.9
     return out
 
 
+def model_stock(deltas: Sequence[np.ndarray], cos_eps: float = 1e-6) -> np.ndarray:
+    """ties.py:137-143: nan_to_num(t * (sum(deltas) / len(deltas))); python's sum() adds in argument order from 0; nan_to_num with
+    torch's defaults (nan -> 0, +-inf -> +-FLT_MAX)."""
+    ds = [_f32(d) for d in deltas]
+    acc = ds[0].copy()
+    for d in ds[1:]:
+        acc = (acc + d).astype(np.float32)
+    w_avg = (acc / np.float32(len(ds))).astype(np.float32)
+    t = model_stock_t(np.stack(ds), cos_eps)
+    with np.errstate(all="ignore"):
+        res = (t * w_avg).astype(np.float32)
+    fmax = np.finfo(np.float32).max
+    return np.nan_to_num(res, nan=0.0, posinf=fmax, neginf=-fmax).astype(np.float32)
+
+
+def dropout(deltas: Sequence[np.ndarray], probability: float = 0.9, rescale: float = 1.0, seed=None, masks=None) -> np.ndarray:
+    """ties.py:202-238 at overlap == 1 (independent masks from numpy's default_rng, :214-217)."""
+    ds = [_f32(d) for d in deltas]
+    if masks is None:
+        rng = np.random.default_rng(seed)
+        masks = [rng.binomial(n=1, p=1 - probability, size=ds[0].shape).astype(bool) for _ in ds]
+    acc = np.zeros_like(ds[0])
+    cnt = np.zeros(ds[0].shape, dtype=np.float32)
+    for m, d in zip(masks, ds):
+        acc = np.where(m, (acc + d).astype(np.float32), acc)
+        cnt = cnt + m.astype(np.float32)
+    if probability == 1.0:
+        rescalar = 1.0
+    else:
+        rescalar = (1.0 - probability) ** rescale
+        rescalar = rescalar if math.isfinite(rescalar) else 1
+    res = (acc / np.maximum(cnt, np.float32(1))).astype(np.float32)
+    out = np.empty_like(res)
+    lib().orc_div_scalar(_p(np.ascontiguousarray(res)), float(np.float32(rescalar)), _p(out), res.size)
+    return out
+
+
 # ----------------------------------------------------------------- LoRA
 def lora_delta(up, down, alpha=None, target_shape=None) -> np.ndarray:
     """extensions/builtin/lycoris.py:226-263: (up.view(out,-1) @ down.view(r,-1)) * (alpha / r or 1)."""

@@ -57,6 +57,8 @@ ties_sum = merge_method(_mm.ties_sum)
 ties_sum_extended = merge_method(_mm.ties_sum_extended)
 ties_sum_with_dropout = merge_method(_mm.ties_sum_with_dropout)
 add_difference_ties = merge_method(_mm.add_difference_ties)
+model_stock = merge_method(_mm.model_stock)
+dropout = merge_method(_mm.dropout)
 cast = merge_method(_mm.cast, reuse_outputs=False)
 omit_non_finite = merge_method(_mm.omit_non_finite, reuse_outputs=False)
 fallback = merge_method(_fallback, identifier="fallback", lazy=("a", "default"), reuse_outputs=False)

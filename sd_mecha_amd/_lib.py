@@ -73,6 +73,9 @@ SIGNATURES = {
     "mecha_ties_sum_with_dropout": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_d, c_i, c_f, c_i, c_p, c_p, c_sz, c_p, c_p]),
     "mecha_ties_extended_workspace_bytes": (c_sz, [c_i, c_i64, c_i64]),
     "mecha_ties_sum_extended": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i64, c_i, c_i, c_d, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_sz, c_p, c_p]),
+    "mecha_model_stock_workspace_bytes": (c_sz, [c_i, c_i64, c_i64]),
+    "mecha_model_stock": (c_i, [c_p, c_i, c_p, c_i64, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p]),
+    "mecha_dropout": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_f, c_p, c_p]),
     "mecha_dare_draw_masks_host": (c_i, [c_u64, c_f, c_i, c_i64, c_p]),
     "mecha_lora_accumulate": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mecha_batched_lora_accumulate": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),

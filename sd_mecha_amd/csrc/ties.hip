@@ -69,6 +69,7 @@ struct TiesParams {
     int64_t mask_words;                    // words per delta row of keep_bits
     int n_deltas;
     int in_dt, out_dt;
+    int raw;                               // model_stock (ties.py:137-143): the stock kernels take the deltas as they are
     int vec_ok;                            // every pointer 16-byte aligned
     const mecha_segment *segs;             // batched: device segment table; else nullptr
     mecha_segment seg0;                    // per key: the one segment
@@ -1211,6 +1212,7 @@ __device__ __forceinline__ void stock_agreeing(const TiesParams &p, int vote_sgn
 #pragma unroll
             for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(g[d][j]);
             if constexpr (DARE) apply_keep_bits(p, d, e, g[d]);
+            if (p.raw) continue;                                                                // model_stock: no filter, no election
             const float thr = __uint_as_float(p.state[d].threshold_bits);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -1218,6 +1220,11 @@ __device__ __forceinline__ void stock_agreeing(const TiesParams &p, int vote_sgn
                 vote[j] += vote_sgn ? g[d][j] : sign_f(g[d][j]);
             }
         }
+    }
+    if (p.raw) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) cnt[j] = (float)p.n_deltas;
+        return;
     }
 #pragma unroll
     for (int d = 0; d < STOCK_MAX; d++) {
@@ -1317,13 +1324,75 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_apply_kernel(TiesParam
             for (int d = 0; d < STOCK_MAX; d++)
                 if (d < p.n_deltas) acc += g[d][j];                                              // filtered_delta.sum(dim=0)
             const float t = (j < valid) ? sp.t[(e + j) / sp.row_len] : 0.0f;
-            float q = (acc * t) / cnt[j];                                                        // ties.py:92
-            if (nonfinite_f32(q)) q = 0.0f;                                                      // nan_to_num
+            float q;
+            if (p.raw) {
+                q = t * (acc / cnt[j]);                                                          // t * (sum(deltas) / len(deltas))  (ties.py:141-143)
+                // torch.nan_to_num with its defaults: nan -> 0, +-inf -> the largest finite fp32 of that sign
+                if (q != q) q = 0.0f;
+                else if (nonfinite_f32(q)) q = __builtin_copysignf(3.4028234663852886e38f, q);
+            } else {
+                q = (acc * t) / cnt[j];                                                          // ties.py:92
+                if (nonfinite_f32(q)) q = 0.0f;                                                  // nan_to_num(nan=0, posinf=0, neginf=0)
+            }
             if (x.has_rescale) q = q / x.rescale_div;                                            // ties.py:50
             bad_out |= (j < valid) && nonfinite_f32(q);
             r[j] = q;
         }
         store_rt(p.out_dt, vec, out, e, valid, r);
+    }
+    if ((bad_in | bad_out) && flags != nullptr)
+        atomicOr(flags, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+}
+
+// ------------------------------------------------------------------------------------------------ dropout (n-supermario)
+// dropout (ties.py:202-238) at odd whole `overlap` (its default 1.0; the other settings go through torch.lerp on numpy arrays
+// upstream and raise): every delta keeps an element where ITS host-drawn Bernoulli mask is set,
+//   out = sum_m (mask_m ? delta_m : 0)  /  max(sum_m mask_m, 1)  /  (1 - probability) ** rescale
+// Sums in index order from +0 (final_delta[mask] += delta[mask], :226-227); two fp32 divisions, as the reference's two `/`.
+struct DropoutParams {
+    const void *in[MECHA_MAX_MODELS];
+    const uint32_t *keep_bits;
+    int64_t mask_words;
+    int n;
+    float rescalar;
+};
+template <int IN_DT, int OUT_DT>
+__global__ __launch_bounds__(MECHA_BLOCK) void dropout_kernel(DropoutParams p, void *out, int64_t numel, bool vec_ok, uint32_t *flags) {
+    const int64_t e = ((int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x) * 8;          // flat grid: one vector position per lane
+    if (e >= numel) return;
+    const int valid = (numel - e >= 8) ? 8 : (int)(numel - e);
+    const bool vec = vec_ok && valid == 8;
+    float acc[8], cnt[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { acc[j] = 0.0f; cnt[j] = 0.0f; }
+    bool bad_in = false;
+    for (int m = 0; m < p.n; m++) {
+        float v[8];
+        if (vec) load8<IN_DT, true>(p.in[m], e, v);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (j < valid) ? load1<IN_DT>(p.in[m], e + j) : 0.0f;
+        }
+        const uint32_t word = p.keep_bits[(int64_t)m * p.mask_words + (e >> 5)];
+        const uint32_t bits8 = (word >> (e & 31)) & 0xffu;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            bad_in |= nonfinite_f32(v[j]);
+            if ((bits8 >> j) & 1u) { acc[j] += v[j]; cnt[j] += 1.0f; }
+        }
+    }
+    float r[8];
+    bool bad_out = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        r[j] = (acc[j] / __builtin_fmaxf(cnt[j], 1.0f)) / p.rescalar;
+        bad_out |= (j < valid) && nonfinite_f32(r[j]);
+    }
+    if (vec) store8<OUT_DT, true>(out, e, r);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < valid) store1<OUT_DT>(out, e + j, r[j]);
     }
     if ((bad_in | bad_out) && flags != nullptr)
         atomicOr(flags, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
@@ -1772,6 +1841,76 @@ int mecha_batched_add_difference_ties(const void *base_arena, const void *const 
     c.k = k; c.alpha = alpha; c.vote_sgn = vote_sgn; c.thresholds_out = thresholds_out; c.workspace = workspace;
     c.workspace_bytes = workspace_bytes; c.flags = seg_flags; c.stream = stream;
     return run_ties(c);
+}
+
+size_t mecha_model_stock_workspace_bytes(int n_models, int64_t numel, int64_t row_len) {
+    if (n_models < 2) n_models = 2;
+    if (row_len < 1) row_len = 1;
+    return stock_bytes(n_models, (numel + row_len - 1) / row_len) + 256;
+}
+
+int mecha_model_stock(const void *const *deltas, int n_models, void *out, int64_t numel, int64_t row_len, int in_dtype, int out_dtype,
+                      float cos_eps, void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(deltas != nullptr && out != nullptr, "NULL argument");
+    MECHA_REQUIRE(n_models >= 2 && n_models <= STOCK_MAX, "model_stock takes 2..%d deltas (got %d): with one, the reference's torch.stack "
+                  "of an empty list of cosines raises", STOCK_MAX, n_models);
+    MECHA_REQUIRE(mecha_valid_dtype(in_dtype) && mecha_valid_dtype(out_dtype), "unknown dtype code");
+    MECHA_REQUIRE(numel >= 0 && row_len >= 1 && numel % row_len == 0, "row_len (%lld) must divide numel (%lld)", (long long)row_len, (long long)numel);
+    if (numel == 0) return MECHA_OK;
+    const int64_t n_rows = numel / row_len;
+    MECHA_REQUIRE(workspace != nullptr && mecha_aligned16(workspace) && workspace_bytes >= stock_bytes(n_models, n_rows),
+                  "model_stock workspace too small or unaligned: need %zu bytes, got %zu", stock_bytes(n_models, n_rows), workspace_bytes);
+    TiesParams p{};
+    bool vec = mecha_aligned16(out);
+    for (int m = 0; m < n_models; m++) {
+        MECHA_REQUIRE(deltas[m] != nullptr, "input %d is NULL", m);
+        p.in[m] = deltas[m];
+        vec = vec && mecha_aligned16(deltas[m]);
+    }
+    p.n_deltas = n_models; p.in_dt = in_dtype; p.out_dt = out_dtype; p.raw = 1; p.vec_ok = vec ? 1 : 0;
+    p.seg0 = mecha_segment{0, numel}; p.n_segs = 1;
+    char *ws = static_cast<char *>(workspace);
+    StockParams sp{};
+    sp.row_len = row_len; sp.n_rows = n_rows; sp.cos_eps = cos_eps;
+    sp.sums = reinterpret_cast<double *>(ws);
+    sp.t = reinterpret_cast<float *>(ws + align_up(sizeof(double) * (size_t)n_rows * (2 * n_models - 1), 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MECHA_CHECK_HIP(hipMemsetAsync(sp.sums, 0, sizeof(double) * (size_t)n_rows * (2 * n_models - 1), s));
+    const int64_t vecs = (numel + 7) / 8;
+    const unsigned sgrid = (unsigned)((vecs + MECHA_BLOCK - 1) / MECHA_BLOCK < MECHA_MAX_GRID ? (vecs + MECHA_BLOCK - 1) / MECHA_BLOCK : MECHA_MAX_GRID);
+    const unsigned tgrid = (unsigned)((n_rows + MECHA_BLOCK - 1) / MECHA_BLOCK);
+    MergeExtra x{};
+    MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_reduce_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, 0, flags);
+    MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, n_models);
+    MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, out, flags);
+    MECHA_CHECK_HIP(hipGetLastError());
+    return MECHA_OK;
+}
+
+int mecha_dropout(const void *const *deltas, int n_models, const uint32_t *keep_bits, void *out, int64_t numel, int in_dtype,
+                  int out_dtype, float rescalar, uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(deltas != nullptr && out != nullptr && keep_bits != nullptr, "NULL argument");
+    MECHA_REQUIRE(n_models >= 1 && n_models <= MECHA_MAX_MODELS, "dropout takes 1..%d deltas (got %d)", MECHA_MAX_MODELS, n_models);
+    MECHA_REQUIRE(mecha_valid_dtype(in_dtype) && mecha_valid_dtype(out_dtype), "unknown dtype code");
+    MECHA_REQUIRE(numel >= 0, "numel must be >= 0");
+    MECHA_REQUIRE(rescalar == rescalar && rescalar != 0.0f, "rescalar must be a non-zero number");
+    if (numel == 0) return MECHA_OK;
+    DropoutParams p{};
+    bool vec = mecha_aligned16(out);
+    for (int m = 0; m < n_models; m++) {
+        MECHA_REQUIRE(deltas[m] != nullptr, "input %d is NULL", m);
+        p.in[m] = deltas[m];
+        vec = vec && mecha_aligned16(deltas[m]);
+    }
+    p.keep_bits = keep_bits; p.mask_words = (numel + 31) / 32; p.n = n_models; p.rescalar = rescalar;
+    const int64_t blocks = ((numel + 7) / 8 + MECHA_BLOCK - 1) / MECHA_BLOCK;
+    MECHA_REQUIRE(blocks <= 0x7fffffff, "numel %lld is beyond one launch", (long long)numel);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MECHA_DISPATCH_DTYPES(in_dtype, out_dtype, {
+        MECHA_LAUNCH(MK_STREAMING, (dropout_kernel<IN_DT, OUT_DT>), dim3((unsigned)blocks), dim3(MECHA_BLOCK), 0, s, p, out, numel, vec, flags);
+    });
+    MECHA_CHECK_HIP(hipGetLastError());
+    return MECHA_OK;
 }
 
 }  // extern "C"

@@ -415,6 +415,85 @@ def ties_sum_with_dropout(*deltas, probability=0.9, della_eps: float = 0.0, resc
     return out
 
 
+def model_stock(*deltas, cos_eps: float = 1e-6, out_dtype=None, flags=None, check_finite=True):
+    """model_stock (ties.py:137-143): nan_to_num(t * (sum(deltas) / n)), t the Model-Stock factor per slice of the last dimension
+    (ties.py:146-159).  2..8 deltas of at least one dimension (the reference raises for one delta and for 0-d keys)."""
+    ds = [_c(d) for d in deltas]
+    _check_inputs(ds, "model_stock")
+    n = len(ds)
+    if ds[0].dim() < 1:
+        raise ValueError("model_stock takes the cosine along the last dimension: 0-d keys have none "
+                         "(torch.nn.CosineSimilarity(dim=-1) raises in the reference)")
+    if not 2 <= n <= 8:
+        raise NotImplementedError(f"model_stock on MI355X takes 2..8 deltas (got {n}; the reference itself raises for 1)")
+    out = _out(ds[0], out_dtype)
+    if out.numel() == 0:
+        return out
+    row_len = ds[0].shape[-1]
+    L = _lib.lib()
+    ws = _workspace(L.mecha_model_stock_workspace_bytes(n, out.numel(), row_len), out.device)
+    fl = _Flags(out.device, flags, check_finite)
+    _lib.check(L.mecha_model_stock(_lib.ptr_array([d.data_ptr() for d in ds]), n, out.data_ptr(), out.numel(), row_len, _DT[ds[0].dtype],
+                                   _DT[out.dtype], float(cos_eps), ws.data_ptr(), ws.numel(), fl.ptr, _stream()), "mecha_model_stock")
+    fl.finish(None)
+    return out
+
+
+def dropout_draw_masks(seed, probability: float, n_models: int, shape, device) -> torch.Tensor:
+    """The masks of ties.py:214-217, drawn on the host the way the reference draws them -- numpy's
+    ``default_rng(seed).binomial(n=1, p=1 - probability, size=shape)`` once per delta, in order -- and bit-packed:
+    int32 [n_models, ceil(numel / 32)], bit (i & 31) of word (i >> 5) = element i."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    numel = int(np.prod(shape, dtype=np.int64))
+    words = (numel + 31) // 32
+    packed = np.zeros((n_models, words * 4), dtype=np.uint8)
+    for m in range(n_models):
+        mask = rng.binomial(n=1, p=1 - probability, size=tuple(shape)).reshape(-1).astype(bool)
+        b = np.packbits(mask, bitorder="little")
+        packed[m, :b.size] = b
+    return torch.from_numpy(packed.view("<u4").view(np.int32).reshape(n_models, words).copy()).to(device)
+
+
+def dropout(*deltas, probability: float = 0.9, rescale: float = 1.0, overlap: float = 1.0, overlap_emphasis: float = 0.0,
+            seed: Optional[int] = None, out_dtype=None, flags=None, check_finite=True, keep_bits: Optional[torch.Tensor] = None):
+    """dropout, "n-supermario" (ties.py:202-238) at odd whole ``overlap`` (the default 1.0): every delta is masked by its own
+    Bernoulli(1 - probability) mask, the kept values are averaged over the masks that kept the element, the result is divided
+    by (1 - probability) ** rescale.  Other ``overlap`` values take the reference through ``torch.lerp`` on numpy arrays
+    (ties.py:268-272), which raises: not supported here either."""
+    if len(deltas) == 0:
+        return 0
+    if not (float(overlap).is_integer() and int(overlap) % 2 == 1):
+        raise NotImplementedError("dropout on MI355X covers odd whole `overlap` (independent masks, the reference default); the "
+                                  "overlapping-set sampler of ties.py:218-223 fails upstream (torch.lerp on numpy arrays)")
+    ds = [_c(d) for d in deltas]
+    _check_inputs(ds, "dropout")
+    if len(ds) > _lib.MAX_MODELS:
+        raise ValueError(f"dropout: at most {_lib.MAX_MODELS} deltas per call")
+    probability = float(probability)
+    out = _out(ds[0], out_dtype)
+    numel = out.numel()
+    if numel == 0:
+        return out
+    if keep_bits is None:
+        keep_bits = dropout_draw_masks(seed, probability, len(ds), ds[0].shape, ds[0].device)
+    if keep_bits.dtype != torch.int32 or tuple(keep_bits.shape) != (len(ds), (numel + 31) // 32) or keep_bits.device != ds[0].device:
+        raise ValueError("keep_bits must be int32 [n_models, ceil(numel/32)] on the deltas' device")
+    if probability == 1.0:                                          # ties.py:231-235
+        rescalar = 1.0
+    else:
+        try:
+            rescalar = (1.0 - probability) ** rescale
+        except (OverflowError, ZeroDivisionError):
+            rescalar = float("inf")
+        rescalar = rescalar if math.isfinite(rescalar) else 1
+    fl = _Flags(out.device, flags, check_finite)
+    _lib.check(_lib.lib().mecha_dropout(_lib.ptr_array([d.data_ptr() for d in ds]), len(ds), _c(keep_bits).data_ptr(), out.data_ptr(), numel,
+                                        _DT[ds[0].dtype], _DT[out.dtype], float(rescalar), fl.ptr, _stream()), "mecha_dropout")
+    fl.finish(None)
+    return out
+
+
 # ------------------------------------------------------------------ lycoris.py
 def _lora_network(up: torch.Tensor, down: torch.Tensor, alpha):
     """(up2d, down2d, rank, scale) of one network: up.view(out, -1), down.view(r, -1), alpha / r or 1 (lycoris.py:228-263)."""

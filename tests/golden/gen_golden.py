@@ -166,6 +166,24 @@ def gen_dare(out):
     out["n_cases"] = np.array(case)
 
 
+def gen_stock_dropout(out):
+    """model_stock (ties.py:137-159) and dropout (ties.py:202-238) through the reference's own bodies."""
+    rng = np.random.default_rng(2718)
+    case = 0
+    for shape in [(16,), (33, 7), (48, 32), (8, 4, 3, 3)]:
+        for n_models in (2, 3, 5):
+            deltas = [torch.from_numpy(rng.normal(0, 0.02, size=shape).astype(np.float32)) for _ in range(n_models)]
+            pre = f"c{case}"
+            out[pre + "_deltas"] = np.stack([bits(d) for d in deltas])
+            out[pre + "_stock"] = bits(ties.model_stock.__wrapped__(*deltas, cos_eps=1e-6))
+            for seed, p, rescale in ((7, 0.9, 1.0), (11, 0.4, 0.5), (3, 0.0, 1.0)):
+                res = ties.dropout.__wrapped__(*deltas, probability=p, rescale=rescale, overlap=1.0, overlap_emphasis=0.0, seed=seed)
+                out[f"{pre}_dropout_s{seed}"] = bits(res)
+            case += 1
+    out["n_cases"] = np.array(case)
+    out["dropout_settings"] = np.array([[7, 0.9, 1.0], [11, 0.4, 0.5], [3, 0.0, 1.0]])
+
+
 def gen_rotate(out):
     rng = np.random.default_rng(360)
     case = 0
@@ -548,7 +566,7 @@ def gen_configs(out):
 def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
     only = set(sys.argv[1:])
-    for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare),
+    for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare), ("stock_dropout", gen_stock_dropout),
                      ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_mixed", gen_e2e_mixed), ("e2e_alias", gen_e2e_alias), ("e2e_lora", gen_e2e_lora), ("mecha_text", gen_mecha_text),
                      ("configs", gen_configs)]:
         if only and name not in only:

@@ -152,6 +152,36 @@ def test_golden_dare(amd, oracle):
     assert amd.ties_sum_with_dropout(torch.zeros(4, device="cuda"), probability=1.0) == 0
 
 
+def test_golden_model_stock_and_dropout(amd, oracle):
+    """Row (f)4: model_stock (ties.py:137-159) and dropout (ties.py:202-238) on the HIP path against the reference's own bodies,
+    and at a larger size against the oracle.  dropout is bit-exact: the masks are drawn on the host with numpy exactly as the
+    reference draws them."""
+    from test_oracle_golden import stock_close
+    g = load_golden("stock_dropout")
+    for c in range(int(g["n_cases"])):
+        pre = f"c{c}"
+        deltas = [dev(d, "float32") for d in g[pre + "_deltas"]]
+        want = f32_from_bits(g[pre + "_stock"]).reshape(deltas[0].shape)
+        assert stock_close(host_f32(amd.model_stock(*deltas)), want), pre
+        for seed, p, rescale in g["dropout_settings"]:
+            got = amd.dropout(*deltas, probability=float(p), rescale=float(rescale), seed=int(seed))
+            want = f32_from_bits(g[f"{pre}_dropout_s{int(seed)}"]).reshape(deltas[0].shape)
+            assert ulp_distance_f32(host_f32(got), want).max() == 0, (pre, seed)
+    rng = np.random.default_rng(5)
+    shape = (640, 2560 + 8)
+    f32 = [oracle.to_f32(oracle.from_f32(rng.normal(0, 0.02, size=shape).astype(np.float32), "bfloat16"), "bfloat16") for _ in range(4)]
+    tens = [torch.from_numpy(x).cuda().to(torch.bfloat16) for x in f32]
+    assert stock_close(host_f32(amd.model_stock(*tens)), oracle.model_stock(f32))
+    got = amd.dropout(*tens, probability=0.9, seed=123, out_dtype=torch.bfloat16)
+    want = oracle.from_f32(oracle.dropout(f32, probability=0.9, seed=123), "bfloat16")
+    assert np.array_equal(got.cpu().view(torch.int16).numpy().view(np.uint16).reshape(-1), want.reshape(-1))
+    assert amd.dropout() == 0
+    with pytest.raises(NotImplementedError):
+        amd.dropout(*tens, overlap=0.5)
+    with pytest.raises(NotImplementedError):
+        amd.model_stock(tens[0])
+
+
 def test_upstream_known_answers_on_gpu(amd):
     """/root/reference/tests/merge_methods/test_ties.py:5-58, run through the HIP path."""
     models = [
