@@ -265,8 +265,9 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
  * svd.py:37-47 stay in the host shim (mecha_allclose_half implements the torch.allclose(a.half(), b.half()) test of :46).
  * Only enqueues on `stream`: nothing is read back, keys on different streams overlap.  A singular value below 1e-7 of
  * the largest (a centred square key has one) ends between 0 and 1 instead of LAPACK's noise-determined +-1.
- * `sweeps_out` (HOST int, may be NULL) receives the number of iteration steps (14 per polar solve: 1 solve for tall,
- * 2 for wide keys; 0 when `transform_in` is given). */
+ * `sweeps_out` (HOST int, may be NULL) receives the number of iteration steps ENQUEUED (14 for the one polar solve of a
+ * tall key; 2 x (6 + 14) for the two solves of a wide key, whose last 14 exit on the device when the first 6 converged;
+ * 0 when `transform_in` is given). */
 size_t mecha_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols);
 int mecha_rotate(const void *a, const void *b, void *out, int64_t n_rows, int64_t n_cols, int in_dtype, int out_dtype,
                  float centralization, void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);
@@ -288,6 +289,19 @@ int mecha_rotate_ex(const void *a, const void *b, void *out, int64_t n_rows, int
                     float centralization, int alignment, float alpha, const float *transform_in, float *transform_out,
                     void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);
 int mecha_allclose_half(const void *a, const void *b, int64_t numel, int in_dtype, uint32_t *not_close, void *stream);
+/* rotate for every key of ONE 2-D shape in one launch sequence (svd.py:10-86 per key; replaces one future per key,
+ * merging.py:223-229, for a recipe rotate(model, model)): the keys lie in the per-model arenas at key_offsets[i] elements
+ * (DEVICE int64[n_keys]); every GEMM, norm and centring launch covers all keys (the key index is a grid dimension), each
+ * key with its own slice of `workspace`.  Wide keys (n_rows < n_cols) first run the 6-step polar schedule made for
+ * [5e-3, 1]; a Gram matrix of the result decides per key, on the device, whether all singular values have arrived, and
+ * only the keys that have not go on through the 14-step schedule (their blocks exit on a per-key word; nothing is read
+ * back).  svd.py:46's allclose(a.half(), b.half()) early-out is evaluated on the device too: such keys get
+ * lerp(a, b, alpha) (svd.py:47).  `seg_flags`: DEVICE uint32[n_keys].  The factor cache is a per-key feature
+ * (mecha_rotate_ex). */
+size_t mecha_batched_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols, int n_keys);
+int mecha_batched_rotate(const void *a_arena, const void *b_arena, void *out_arena, const int64_t *key_offsets, int n_keys,
+                         int64_t n_rows, int64_t n_cols, int in_dtype, int out_dtype, float centralization, int alignment,
+                         float alpha, void *workspace, size_t workspace_bytes, uint32_t *seg_flags, void *stream);
 
 /* ------------------------------------------------------------------ batched
  * The key scheduler's form (replaces the per-key futures loop of merging.py:223-229

@@ -24,12 +24,29 @@
 // Frobenius error (wide keys with centring: on the component the reference determines, DESIGN.md "rotate: reference
 // indeterminacy").  Roofline: MFMA (f32).  Flops, with q = min(n, p), c = max over the polar solves' column count:
 // 2 n p^2 for each of the A^T B contraction and the final application, 4 q^2 c per Newton-Schulz iteration.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A launch covers `count` keys of ONE 2-D shape.  Every key has the same private workspace layout, `ws_bytes` apart, so a
+// workspace pointer of key g is the pointer of key 0 plus g * ws_bytes; the tensors themselves sit in the per-model arenas at
+// offs[g] elements (nullptr: one key at offset 0).  `skip` (nullable): per-key device words; a block whose key's word is
+// non-zero exits at once -- how the keys of a batch that have converged leave the later polar steps without the host
+// learning about it.
+struct Batch {
+    int count;
+    int64_t ws_bytes;
+    const int64_t *offs;
+    const uint32_t *skip;
+};
+template <typename T> __device__ __forceinline__ T *key_ptr(T *p, const Batch &bt, int key) {
+    return p == nullptr ? nullptr : reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(p)) + (int64_t)key * bt.ws_bytes);
+}
+__device__ __forceinline__ int64_t key_off(const Batch &bt, int key) { return bt.offs != nullptr ? bt.offs[key] : 0; }
 
 // ------------------------------------------------------------------------------------------------ centring
 __device__ __forceinline__ float ld_any(int dt, const void *p, int64_t i) {
@@ -38,7 +55,11 @@ __device__ __forceinline__ float ld_any(int dt, const void *p, int64_t i) {
 
 // partial column sums: grid (ceil(p/64), chunks); block 256 = 4 row lanes x 64 columns
 __global__ __launch_bounds__(256) void rot_colsum_kernel(const void *a, const void *b, int dt, int64_t n, int64_t p, int chunks,
-                                                         double *part /* [2][chunks][p] */, uint32_t *flags) {
+                                                         double *part /* [2][chunks][p] */, uint32_t *flags, Batch bt) {
+    const int key = blockIdx.z;
+    const int64_t base = key_off(bt, key);
+    part = key_ptr(part, bt, key);
+    if (flags != nullptr) flags += key;
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + c;
     const int64_t rows_per = (n + chunks - 1) / chunks;
@@ -47,7 +68,7 @@ __global__ __launch_bounds__(256) void rot_colsum_kernel(const void *a, const vo
     bool bad = false;
     if (col < p) {
         for (int64_t r = r0 + rl; r < r1; r += 4) {
-            const float x = ld_any(dt, a, r * p + col), y = ld_any(dt, b, r * p + col);
+            const float x = ld_any(dt, a, base + r * p + col), y = ld_any(dt, b, base + r * p + col);
             bad |= nonfinite_f32(x) | nonfinite_f32(y);
             sa += (double)x; sb += (double)y;
         }
@@ -63,7 +84,9 @@ __global__ __launch_bounds__(256) void rot_colsum_kernel(const void *a, const vo
 }
 
 __global__ __launch_bounds__(256) void rot_means_kernel(const double *part, int chunks, int64_t n, int64_t p, float cz, float t,
-                                                        float *a_mean, float *b_mean, float *t_mean) {
+                                                        float *a_mean, float *b_mean, float *t_mean, Batch bt) {
+    const int key = blockIdx.y;
+    part = key_ptr(part, bt, key); a_mean = key_ptr(a_mean, bt, key); b_mean = key_ptr(b_mean, bt, key); t_mean = key_ptr(t_mean, bt, key);
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= p) return;
     double sa = 0.0, sb = 0.0;
@@ -76,12 +99,15 @@ __global__ __launch_bounds__(256) void rot_means_kernel(const double *part, int 
 }
 
 __global__ __launch_bounds__(256) void rot_center_kernel(const void *a, const void *b, int dt, int64_t n, int64_t p, const float *a_mean,
-                                                         const float *b_mean, float *ac, float *bc) {
+                                                         const float *b_mean, float *ac, float *bc, Batch bt) {
+    const int key = blockIdx.y;
+    const int64_t base = key_off(bt, key);
+    a_mean = key_ptr(a_mean, bt, key); b_mean = key_ptr(b_mean, bt, key); ac = key_ptr(ac, bt, key); bc = key_ptr(bc, bt, key);
     const int64_t total = n * p;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t c = i % p;
-        ac[i] = ld_any(dt, a, i) - a_mean[c];             // a_2d - a_mean  (svd.py:69-70)
-        bc[i] = ld_any(dt, b, i) - b_mean[c];
+        ac[i] = ld_any(dt, a, base + i) - a_mean[c];      // a_2d - a_mean  (svd.py:69-70)
+        bc[i] = ld_any(dt, b, base + i) - b_mean[c];
     }
 }
 
@@ -100,7 +126,16 @@ struct GemmEpilogue {
     float axpy_a, axpy_b;
     const float *mix;           // if set: v = mix_w0 * mix[idx] + mix_w1 * v, after minus / plus (the alpha interpolation, svd.py:82)
     float mix_w0, mix_w1;
+    int64_t out_off;            // element offset of this key inside `out` (set per block from the batch descriptor)
 };
+// the epilogue of key `key` of a batch: workspace pointers move by the key's workspace stride, `out` by its arena offset
+__device__ __forceinline__ GemmEpilogue epilogue_for_key(GemmEpilogue e, const Batch &bt, int key) {
+    e.minus = key_ptr(e.minus, bt, key); e.plus = key_ptr(e.plus, bt, key); e.col_bias = key_ptr(e.col_bias, bt, key);
+    e.axpy = key_ptr(e.axpy, bt, key); e.mix = key_ptr(e.mix, bt, key);
+    e.out_off = key_off(bt, key);
+    if (e.flags != nullptr) e.flags += key;
+    return e;
+}
 
 __device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int64_t ldc, int64_t row, int64_t col, float v, bool &bad) {
     const int64_t idx = row * ldc + col;
@@ -111,9 +146,9 @@ __device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int6
     if (e.col_bias != nullptr) v = v + e.col_bias[col];
     if (e.out != nullptr) {
         bad |= nonfinite_f32(v);
-        if (e.out_dt == MECHA_BF16) store1<MECHA_BF16>(e.out, idx, v);
-        else if (e.out_dt == MECHA_F16) store1<MECHA_F16>(e.out, idx, v);
-        else store1<MECHA_F32>(e.out, idx, v);
+        if (e.out_dt == MECHA_BF16) store1<MECHA_BF16>(e.out, e.out_off + idx, v);
+        else if (e.out_dt == MECHA_F16) store1<MECHA_F16>(e.out, e.out_off + idx, v);
+        else store1<MECHA_F32>(e.out, e.out_off + idx, v);
     } else c[idx] = v;
 }
 
@@ -181,15 +216,18 @@ __device__ __forceinline__ void tile_store(const Operand &op, const TileRegs &t,
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab,
+__global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab, int n_slabs, Batch bt,
                                                    GemmEpilogue e) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][GK * GP];       // [buffer][A | B]
+    const int key = blockIdx.z / n_slabs, slab = blockIdx.z - key * n_slabs;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    A.p = key_ptr(A.p, bt, key); B.p = key_ptr(B.p, bt, key); C = key_ptr(C, bt, key);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kk = lane >> 5;
     const int64_t bm0 = (int64_t)blockIdx.y * 64, bn0 = (int64_t)blockIdx.x * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int64_t m0 = bm0 + wm, n0 = bn0 + wn;
-    const int64_t k_begin = (int64_t)blockIdx.z * k_per_slab;
+    const int64_t k_begin = (int64_t)slab * k_per_slab;
     const int64_t k_end = (k_begin + k_per_slab < K) ? k_begin + k_per_slab : K;
     f32x16 acc;
 #pragma unroll
@@ -211,16 +249,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, float *
         __syncthreads();
         buf ^= 1;
     }
-    float *c = C + (int64_t)blockIdx.z * M * N;
-    GemmEpilogue ee = e;
-    if (gridDim.z > 1) ee = GemmEpilogue{};                     // the epilogue then runs in gemm_reduce
+    float *c = C + (int64_t)slab * M * N;
+    GemmEpilogue ee = epilogue_for_key(e, bt, key);
+    if (n_slabs > 1) ee = GemmEpilogue{};                       // the epilogue then runs in gemm_reduce
     bool bad = false;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kk, col = n0 + i;
         if (row < M && col < N) gemm_store(ee, c, N, row, col, acc[r], bad);
     }
-    if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
+    if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
 // The same product for outputs of at least 256 x 256: block tile 128 x 128, wave tile 64 x 64 = 2 x 2 accumulators.  Every LDS
@@ -286,14 +324,17 @@ __device__ __forceinline__ void tile_store128(const Operand &op, const TileRegs 
     }
 }
 
-__global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab,
+__global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab, int n_slabs, Batch bt,
                                                       GemmEpilogue e) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][GK2 * GP2];     // [buffer][A | B]
+    const int key = blockIdx.z / n_slabs, slab = blockIdx.z - key * n_slabs;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    A.p = key_ptr(A.p, bt, key); B.p = key_ptr(B.p, bt, key); C = key_ptr(C, bt, key);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kk = lane >> 5;
     const int64_t bm0 = (int64_t)blockIdx.y * 128, bn0 = (int64_t)blockIdx.x * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int64_t k_begin = (int64_t)blockIdx.z * k_per_slab;
+    const int64_t k_begin = (int64_t)slab * k_per_slab;
     const int64_t k_end = (k_begin + k_per_slab < K) ? k_begin + k_per_slab : K;
     f32x16 acc[2][2];
 #pragma unroll
@@ -327,9 +368,9 @@ __global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, floa
         __syncthreads();
         buf ^= 1;
     }
-    float *c = C + (int64_t)blockIdx.z * M * N;
-    GemmEpilogue ee = e;
-    if (gridDim.z > 1) ee = GemmEpilogue{};                     // the epilogue then runs in gemm_reduce
+    float *c = C + (int64_t)slab * M * N;
+    GemmEpilogue ee = epilogue_for_key(e, bt, key);
+    if (n_slabs > 1) ee = GemmEpilogue{};                       // the epilogue then runs in gemm_reduce
     bool bad = false;
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
@@ -340,10 +381,14 @@ __global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, floa
                 const int64_t row = bm0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * kk, col = bn0 + wn + 32 * tn + i;
                 if (row < M && col < N) gemm_store(ee, c, N, row, col, acc[tm][tn][r], bad);
             }
-    if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
+    if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, int n_slabs, float *C, int64_t M, int64_t N, GemmEpilogue e) {
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, int n_slabs, float *C, int64_t M, int64_t N, GemmEpilogue e, Batch bt) {
+    const int key = blockIdx.y;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    slabs = key_ptr(slabs, bt, key); C = key_ptr(C, bt, key);
+    e = epilogue_for_key(e, bt, key);
     const int64_t total = M * N;
     bool bad = false;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -357,8 +402,11 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
 
 // ------------------------------------------------------------------------------------------------ polar factor
 // scal[0] += sum G^2, scal[1] += sum (G - I)^2 over the r x r Gram matrix G (fp64 accumulation; scal zeroed by the host)
-__global__ __launch_bounds__(256) void rot_gram_norms_kernel(const float *g, int64_t r, double *scal) {
+__global__ __launch_bounds__(256) void rot_gram_norms_kernel(const float *g, int64_t r, double *scal, Batch bt) {
     __shared__ double sh[2][4];
+    const int key = blockIdx.y;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    g = key_ptr(g, bt, key); scal = key_ptr(scal, bt, key);
     const int64_t total = r * r;
     double s0 = 0.0, s1 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -378,10 +426,13 @@ __global__ __launch_bounds__(256) void rot_gram_norms_kernel(const float *g, int
 }
 
 // torch.allclose(a.half(), b.half())  (svd.py:46): |a - b| <= 1e-8 + 1e-5 |b| on the fp16-rounded values
-__global__ __launch_bounds__(256) void rot_allclose_kernel(const void *a, const void *b, int dt, int64_t n, unsigned int *not_close) {
+__global__ __launch_bounds__(256) void rot_allclose_kernel(const void *a, const void *b, int dt, int64_t n, unsigned int *not_close, Batch bt) {
+    const int key = blockIdx.y;
+    const int64_t base = key_off(bt, key);
+    not_close += key;
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float x = (float)(_Float16)ld_any(dt, a, i), y = (float)(_Float16)ld_any(dt, b, i);
+        const float x = (float)(_Float16)ld_any(dt, a, base + i), y = (float)(_Float16)ld_any(dt, b, base + i);
         const bool close = (x == y) || (__builtin_fabsf(x - y) <= 1e-8f + 1e-5f * __builtin_fabsf(y));
         bad |= !close;
     }
@@ -391,63 +442,44 @@ __global__ __launch_bounds__(256) void rot_allclose_kernel(const void *a, const 
 // ------------------------------------------------------------------------------------------------ host
 size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
-struct Bump {
-    char *base; size_t off;
-    template <typename T> T *take(size_t count) {
-        T *p = reinterpret_cast<T *>(base + off);
-        off = up256(off + count * sizeof(T));
-        return p;
-    }
+constexpr size_t SLAB_FLOATS = (size_t)4096 * 64 * 64;          // most split-K slab floats one launch may use (all its keys together)
+constexpr int GRID_Z_MAX = 65535;
+
+// What a product needs beyond its operands: the key batch, the split-K slab area of key 0 and its size per key.
+struct GemmCtx {
+    Batch bt;
+    float *slabs;
+    size_t slab_floats;
+    hipStream_t s;
 };
+const Batch ONE_KEY{1, 0, nullptr, nullptr};
 
-constexpr size_t SLAB_FLOATS = (size_t)4096 * 64 * 64;          // split-K only for outputs of at most one 64 x 64 tile... see below
-
-int split_k_slabs(int64_t M, int64_t N, int64_t K) {
-    const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    int64_t z = (1024 + tiles - 1) / tiles;
-    const int64_t zmax = (K + 255) / 256;
+void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, const GemmEpilogue &e, const GemmCtx &g) {
+    const int count = g.bt.count;
+    const bool big = M >= 256 && N >= 256;
+    const int64_t T = big ? 128 : 64;                           // block tile
+    const int64_t tiles = ((M + T - 1) / T) * ((N + T - 1) / T) * count;
+    // split K so that the launch fills the machine: about two resident 128 x 128 blocks per CU (512 on 256 CUs; 256 and 1024
+    // measured slower), four 64 x 64 ones.  A batch of keys brings its own parallelism: the slabs shrink as the batch grows.
+    int64_t z = big ? 512 / tiles : (1024 + tiles - 1) / tiles;
+    const int64_t zmax = big ? (K + 127) / 128 : (K + 255) / 256;
     if (z > zmax) z = zmax;
-    while (z > 1 && (size_t)z * (size_t)M * (size_t)N > SLAB_FLOATS) z--;
+    if (z > GRID_Z_MAX / count) z = GRID_Z_MAX / count;
+    while (z > 1 && (size_t)z * (size_t)M * (size_t)N > g.slab_floats) z--;
     if (z < 1) z = 1;
-    return (int)z;
-}
-
-void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, float *slabs, const GemmEpilogue &e, hipStream_t s) {
-    if (M >= 256 && N >= 256) {
-        // 128 x 128 tiles; split K so that about two blocks per CU are resident (512 on 256 CUs; 256 and 1024 measured slower)
-        const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        int64_t z = 512 / tiles;
-        const int64_t zmax = (K + 127) / 128;
-        if (z > zmax) z = zmax;
-        while (z > 1 && (size_t)z * (size_t)M * (size_t)N > SLAB_FLOATS) z--;
-        if (z < 1) z = 1;
-        int64_t k_per = (K + z - 1) / z;
-        k_per = (k_per + GK2 - 1) / GK2 * GK2;                  // whole k-chunks per slab (keeps 16-byte loads along k aligned)
-        z = (K + k_per - 1) / k_per;
-        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)z), block(256);
-        if (z == 1) {
-            MECHA_LAUNCH(MK_ROT_GEMM, gemm128_kernel, grid, block, 0, s, A, B, C, M, N, K, k_per, e);
-        } else {
-            GemmEpilogue none{};
-            MECHA_LAUNCH(MK_ROT_GEMM, gemm128_kernel, grid, block, 0, s, A, B, slabs, M, N, K, k_per, none);
-            const int64_t total = M * N;
-            const unsigned rb = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-            MECHA_LAUNCH(MK_ROT_GEMM, gemm_reduce_kernel, dim3(rb), dim3(256), 0, s, slabs, (int)z, C, M, N, e);
-        }
-        return;
-    }
-    const int z = split_k_slabs(M, N, K);
     int64_t k_per = (K + z - 1) / z;
-    k_per = (k_per + 1) / 2 * 2;                                // the MFMA consumes k in pairs
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)z), block(256);
-    if (z == 1) {
-        MECHA_LAUNCH(MK_ROT_GEMM, gemm_kernel, grid, block, 0, s, A, B, C, M, N, K, k_per, e);
-    } else {
-        GemmEpilogue none{};
-        MECHA_LAUNCH(MK_ROT_GEMM, gemm_kernel, grid, block, 0, s, A, B, slabs, M, N, K, k_per, none);
+    if (big) k_per = (k_per + GK2 - 1) / GK2 * GK2;             // whole k-chunks per slab (keeps 16-byte loads along k aligned)
+    else k_per = (k_per + 1) / 2 * 2;                           // the MFMA consumes k in pairs
+    z = (K + k_per - 1) / k_per;
+    dim3 grid((unsigned)((N + T - 1) / T), (unsigned)((M + T - 1) / T), (unsigned)(z * count)), block(256);
+    float *dst = z == 1 ? C : g.slabs;
+    const GemmEpilogue none{};
+    if (big) MECHA_LAUNCH(MK_ROT_GEMM, gemm128_kernel, grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none);
+    else MECHA_LAUNCH(MK_ROT_GEMM, gemm_kernel, grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none);
+    if (z > 1) {
         const int64_t total = M * N;
-        const unsigned rb = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-        MECHA_LAUNCH(MK_ROT_GEMM, gemm_reduce_kernel, dim3(rb), dim3(256), 0, s, slabs, z, C, M, N, e);
+        const int64_t want = (total + 255) / 256, cap = count >= 64 ? 16 : 1024 / count;
+        MECHA_LAUNCH(MK_ROT_GEMM, gemm_reduce_kernel, dim3((unsigned)(want < cap ? want : cap), (unsigned)count), dim3(256), 0, g.s, g.slabs, (int)z, C, M, N, e, g.bt);
     }
 }
 
@@ -504,29 +536,41 @@ void remez_odd5(double l, double &a, double &b, double &c, double &E) {
 // factor).  So a step is never made for a ratio below POLAR_CUSHION: values above that fraction of the largest stay within
 // [0.21, 1.79] of it, values below still grow 3.86x a step (4.26x without the cushion), 14 steps in all from 1e-7.
 constexpr double POLAR_CUSHION = 0.1;
+PolarSchedule build_polar_schedule(double l0) {
+    PolarSchedule ps{};
+    double l = l0, u = 1.0;
+    for (ps.n = 0; ps.n < POLAR_MAX_STEPS;) {
+        const bool cushioned = l / u < POLAR_CUSHION;
+        const double rho = cushioned ? POLAR_CUSHION : l / u;
+        double a, b, c, E;
+        remez_odd5(rho, a, b, c, E);                          // on x / u
+        const double u2 = u * u;
+        ps.step[ps.n++] = PolarStep{(float)(a / u), (float)(b / (u * u2)), (float)(c / (u * u2 * u2))};
+        if (!cushioned && E < 1e-6) break;                    // the next interval would be below fp32 resolution
+        const double x = l / u, x2 = x * x, pl = x * (a + x2 * (b + x2 * c));   // the step rises monotonically on [0, rho u]
+        l = (cushioned && pl < 1.0 - E) ? pl : 1.0 - E;
+        u = (1.0 + E) * (1.0 + 1e-6);                         // a hair of room for the rounding of the products
+    }
+    return ps;
+}
 const PolarSchedule &polar_schedule() {
-    static const PolarSchedule sched = [] {
-        PolarSchedule ps{};
-        double l = 1e-7, u = 1.0;
-        for (ps.n = 0; ps.n < POLAR_MAX_STEPS;) {
-            const bool cushioned = l / u < POLAR_CUSHION;
-            const double rho = cushioned ? POLAR_CUSHION : l / u;
-            double a, b, c, E;
-            remez_odd5(rho, a, b, c, E);                          // on x / u
-            const double u2 = u * u;
-            ps.step[ps.n++] = PolarStep{(float)(a / u), (float)(b / (u * u2)), (float)(c / (u * u2 * u2))};
-            if (!cushioned && E < 1e-6) break;                    // the next interval would be below fp32 resolution
-            const double x = l / u, x2 = x * x, pl = x * (a + x2 * (b + x2 * c));   // the step rises monotonically on [0, rho u]
-            l = (cushioned && pl < 1.0 - E) ? pl : 1.0 - E;
-            u = (1.0 + E) * (1.0 + 1e-6);                         // a hair of room for the rounding of the products
-        }
-        return ps;
-    }();
+    static const PolarSchedule sched = build_polar_schedule(1e-7);
+    return sched;
+}
+// The short schedule of the optimistic first phase (polar_newton_schulz): singular values down to POLAR_EASY_L of the scaled
+// matrix's bound.  The scaling by |X X^T|_F^(-1/2) puts the largest singular value between r^(-1/4) and 1 (0.17 for 1280 rows),
+// so 5e-3 covers condition numbers up to ~35 at that size -- a Gaussian 1280 x 2048 matrix has 9, 1280 x 5120 has 3.
+constexpr double POLAR_EASY_L = 5e-3;
+const PolarSchedule &polar_schedule_easy() {
+    static const PolarSchedule sched = build_polar_schedule(POLAR_EASY_L);
     return sched;
 }
 
 // X *= s, G *= s^2 with s = (sum G^2)^(-1/4) read from scal[0] on the device (0 for a zero matrix: it stays zero)
-__global__ __launch_bounds__(256) void rot_polar_scale_kernel(float *x, int64_t nx, float *g, int64_t ng, const double *scal) {
+__global__ __launch_bounds__(256) void rot_polar_scale_kernel(float *x, int64_t nx, float *g, int64_t ng, const double *scal, Batch bt) {
+    const int key = blockIdx.y;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    x = key_ptr(x, bt, key); g = key_ptr(g, bt, key); scal = key_ptr(scal, bt, key);
     const double h = scal[0];
     const float s = (h > 0.0 && h < 1e300) ? (float)(1.0 / sqrt(sqrt(h))) : (h == h ? 0.0f : __uint_as_float(0x7fc00000u));
     const float s2 = s * s;
@@ -542,8 +586,11 @@ __global__ __launch_bounds__(256) void rot_polar_scale_kernel(float *x, int64_t 
 // Removing it every few steps keeps the zero singular value at rounding level, so the factor is the one of the rank-(r - 1)
 // matrix (the minimum-norm member of the reference's family, DESIGN.md "rotate: reference indeterminacy").
 // One block per 64 columns: 4 row groups x 64 columns, fp64 partial sums through LDS.
-__global__ __launch_bounds__(256) void rot_deflate_ones_kernel(float *x, int64_t r, int64_t c) {
+__global__ __launch_bounds__(256) void rot_deflate_ones_kernel(float *x, int64_t r, int64_t c, Batch bt) {
     __shared__ double part[4][64];
+    const int key = blockIdx.y;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    x = key_ptr(x, bt, key);
     const int col_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + col_l;
     double sum = 0.0;
@@ -557,50 +604,328 @@ __global__ __launch_bounds__(256) void rot_deflate_ones_kernel(float *x, int64_t
 }
 constexpr int POLAR_DEFLATE_EVERY = 3;
 
-int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, int64_t c, double *scal, float *slabs, int *iters_out, hipStream_t s,
-                        bool deflate_ones = false) {
-    float *cur = X, *nxt = tmp;
+// done[key] = 1 when the Gram matrix whose norms sit in scal says the key's polar iteration has converged:
+// |G - I|_F^2 <= null + tol, `null` = the number of exactly-zero singular values the key is known to have (the deflated
+// all-ones direction of a fully centred wide key).  One thread per key.
+__global__ __launch_bounds__(64) void rot_converged_kernel(const double *scal, double null_dirs, double tol, uint32_t *done, Batch bt) {
+    const int key = blockIdx.x * 64 + threadIdx.x;
+    if (key >= bt.count) return;
+    const double err2 = key_ptr(scal, bt, key)[1];
+    done[key] = (err2 == err2 && err2 <= null_dirs + tol) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(64) void rot_zero_scal_kernel(double *scal, Batch bt) {
+    const int key = blockIdx.x * 64 + threadIdx.x;
+    if (key < bt.count) { double *s = key_ptr(scal, bt, key); s[0] = 0.0; s[1] = 0.0; }
+}
+// scal[0] = |G|_F^2, scal[1] = |G - I|_F^2 of every key's r x r Gram matrix
+void gram_norms(const float *G, int64_t r, double *scal, const GemmCtx &g) {
+    const int count = g.bt.count;
+    MECHA_LAUNCH(MK_ROT_NORMS, rot_zero_scal_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, g.s, scal, g.bt);
+    const int64_t nbw = (r * r + 255) / 256, nb_cap = count >= 64 ? 16 : 1024 / count;
+    MECHA_LAUNCH(MK_ROT_NORMS, rot_gram_norms_kernel, dim3((unsigned)(nbw < nb_cap ? nbw : nb_cap), (unsigned)count), dim3(256), 0, g.s, G, r, scal, g.bt);
+}
+
+// One step X <- a X + (b G + c G^2) X on every key of the batch that `g.bt.skip` does not excuse; returns the new current buffer.
+// first: the scaling by |X X^T|_F^(-1/2) (see above) happens on this step's Gram matrix.
+float *polar_step(float *cur, float *nxt, float *G, float *G2, int64_t r, int64_t c, double *scal, const PolarStep &st, bool first,
+                  const GemmCtx &g) {
     const int64_t rr = r * r;
-    const unsigned nb = (unsigned)((rr + 255) / 256 < 1024 ? (rr + 255) / 256 : 1024);
+    const int count = g.bt.count;
     const GemmEpilogue none{};
-    const PolarSchedule &ps = polar_schedule();
-    for (int it = 0; it < ps.n; it++) {
-        // G[m][n] = sum_k cur[m][k] cur[n][k]
-        gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, slabs, none, s);
-        if (it == 0) {
-            MECHA_CHECK_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), s));
-            MECHA_LAUNCH(MK_ROT_NORMS, rot_gram_norms_kernel, dim3(nb), dim3(256), 0, s, G, r, scal);
-            const int64_t both = r * c + rr;
-            const unsigned sb = (unsigned)((both + 255) / 256 < 2048 ? (both + 255) / 256 : 2048);
-            MECHA_LAUNCH(MK_ROT_NORMS, rot_polar_scale_kernel, dim3(sb), dim3(256), 0, s, cur, r * c, G, rr, scal);
-        }
-        // G2 = b G + c G G;  nxt = a cur + G2 cur
-        GemmEpilogue mix{};
-        mix.axpy = G; mix.axpy_a = ps.step[it].b; mix.axpy_b = ps.step[it].c;
-        // (G and b G + c G G are symmetric bit for bit -- the same products in the same order on both sides of the diagonal --
-        //  so both operands are read along their rows: contiguous 16-byte loads)
-        gemm(Operand{G, r, 1}, Operand{G, r, 1}, G2, r, r, r, slabs, mix, s);
-        GemmEpilogue upd{};
-        upd.axpy = cur; upd.axpy_a = ps.step[it].a; upd.axpy_b = 1.0f;
-        gemm(Operand{G2, r, 1}, Operand{cur, c, 1}, nxt, r, c, r, slabs, upd, s);
-        float *t = cur; cur = nxt; nxt = t;
-        if (deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == ps.n))
-            MECHA_LAUNCH(MK_ROT_NORMS, rot_deflate_ones_kernel, dim3((unsigned)((c + 63) / 64)), dim3(256), 0, s, cur, r, c);
+    // G[m][n] = sum_k cur[m][k] cur[n][k]
+    gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g);
+    if (first) {
+        gram_norms(G, r, scal, g);
+        const int64_t both = r * c + rr;
+        const int64_t sbw = (both + 255) / 256, sb_cap = count >= 64 ? 32 : 2048 / count;
+        MECHA_LAUNCH(MK_ROT_NORMS, rot_polar_scale_kernel, dim3((unsigned)(sbw < sb_cap ? sbw : sb_cap), (unsigned)count), dim3(256), 0, g.s, cur, r * c, G, rr,
+                     scal, g.bt);
     }
-    if (iters_out) *iters_out += ps.n;
-    if (cur != X) MECHA_CHECK_HIP(hipMemcpyAsync(X, cur, sizeof(float) * r * c, hipMemcpyDeviceToDevice, s));
+    // G2 = b G + c G G;  nxt = a cur + G2 cur
+    GemmEpilogue mix{};
+    mix.axpy = G; mix.axpy_a = st.b; mix.axpy_b = st.c;
+    // (G and b G + c G G are symmetric bit for bit -- the same products in the same order on both sides of the diagonal --
+    //  so both operands are read along their rows: contiguous 16-byte loads)
+    gemm(Operand{G, r, 1}, Operand{G, r, 1}, G2, r, r, r, mix, g);
+    GemmEpilogue upd{};
+    upd.axpy = cur; upd.axpy_a = st.a; upd.axpy_b = 1.0f;
+    gemm(Operand{G2, r, 1}, Operand{cur, c, 1}, nxt, r, c, r, upd, g);
+    return nxt;
+}
+
+// Polar factor of every key's X (r x c, r <= c), in place.
+//   optimistic == false: the 14-step schedule made for singular values down to 1e-7 of the largest.
+//   optimistic == true (wide keys: well conditioned as a rule -- a Gaussian n x p matrix has all its singular values
+//       within (sqrt(p) +- sqrt(n)) sigma): first the short schedule made for [POLAR_EASY_L, 1]; then a Gram matrix of the
+//       result tells, per key and on the device, whether every singular value has arrived (rot_converged_kernel); keys
+//       that have leave, the others go through the long schedule as well (every step maps (0, u] into (0, u']: running
+//       it on a matrix that is already partly converged is safe).  The host never learns which keys left: the later
+//       launches are enqueued for the whole batch and their blocks exit on the key's done word.
+// done: per-key device words (used only when optimistic).
+int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, int64_t c, double *scal, uint32_t *done, int *iters_out,
+                        const GemmCtx &g_in, bool deflate_ones, bool optimistic) {
+    GemmCtx g = g_in;
+    // MECHA_ROT_POLAR=long: no optimistic phase; =both: every key goes through both schedules (tests of the fall-through)
+    const char *mode = getenv("MECHA_ROT_POLAR");
+    if (mode != nullptr && strcmp(mode, "long") == 0) optimistic = false;
+    const bool force_both = mode != nullptr && strcmp(mode, "both") == 0;
+    float *cur = X, *nxt = tmp;
+    const int count = g.bt.count;
+    auto deflate = [&](int it, int n_steps) {
+        if (deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == n_steps))
+            MECHA_LAUNCH(MK_ROT_NORMS, rot_deflate_ones_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)count), dim3(256), 0, g.s, cur, r, c, g.bt);
+    };
+    int steps = 0;
+    bool first = true;
+    if (optimistic) {
+        const PolarSchedule &easy = polar_schedule_easy();
+        for (int it = 0; it < easy.n; it++) {
+            float *out = polar_step(cur, nxt, G, G2, r, c, scal, easy.step[it], first, g);
+            nxt = cur; cur = out; first = false;
+            deflate(it, easy.n);
+        }
+        steps += easy.n;
+        // has every singular value arrived?  G of the current X, its distance from the identity, one word per key
+        const GemmEpilogue none{};
+        gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g);
+        gram_norms(G, r, scal, g);
+        // |G - I|_F^2 = sum (sigma^2 - 1)^2: 1e-9 r allows an rms deviation of 1.6e-5 per singular value; 1e-13 r^2 is the
+        // rounding floor of the fp32 Gram matrix itself
+        // (+ 4e-6 beside a deflated direction: the 1 it contributes is a sum of r^2 rounded entries of size 1 / r)
+        const double tol = 1e-9 * (double)r + 1e-13 * (double)r * (double)r + (deflate_ones ? 4e-6 : 0.0);
+        MECHA_LAUNCH(MK_ROT_NORMS, rot_converged_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, g.s, scal, deflate_ones ? 1.0 : 0.0, tol, done, g.bt);
+        // keys that are done must end in X: copy now if the short schedule ended in the twin buffer
+        if (cur != X) {
+            MECHA_CHECK_HIP(hipMemcpy2DAsync(X, (size_t)(g.bt.ws_bytes ? g.bt.ws_bytes : sizeof(float) * r * c), cur,
+                                             (size_t)(g.bt.ws_bytes ? g.bt.ws_bytes : sizeof(float) * r * c), sizeof(float) * r * c, (size_t)count,
+                                             hipMemcpyDeviceToDevice, g.s));
+            cur = X; nxt = tmp;
+        }
+        g.bt.skip = done;
+    }
+    const PolarSchedule &ps = polar_schedule();
+    if (force_both) g.bt.skip = nullptr;
+    for (int it = 0; it < ps.n; it++) {
+        PolarStep st = ps.step[it];
+        if (it == 0 && !first) {
+            // The long schedule leaves a hair (1e-6) of room above its upper bounds, enough for a matrix scaled below 1 by
+            // its own norm; one that arrives from the short schedule has singular values at 1 +- 1e-6, some of them above
+            // 1, and the repeated cushioned step throws anything above its bound out (1 + 1e-5 overflows after 8 steps).
+            // So the first step is taken on 0.97 X: p(0.97 x) = (0.97 a) x + (0.97^3 b) x^3 + (0.97^5 c) x^5.
+            const float h = 0.97f, h3 = h * h * h;
+            st = PolarStep{st.a * h, st.b * h3, st.c * h3 * h * h};
+        }
+        float *out = polar_step(cur, nxt, G, G2, r, c, scal, st, first, g);
+        nxt = cur; cur = out; first = false;
+        deflate(it, ps.n);
+    }
+    steps += ps.n;
+    if (iters_out) *iters_out += steps;
+    if (cur != X) {
+        // (an odd number of steps; keys excused by `done` hold their result in X already, and their stale twin must not
+        //  overwrite it: the schedules have an even number of steps, checked where they are built)
+        mecha_set_error("polar schedule with an odd number of steps");
+        return MECHA_ERR_ARG;
+    }
     return MECHA_OK;
 }
 
-size_t rotate_workspace_bytes_impl(int64_t n, int64_t p) {
+// Private workspace of one key, as offsets from its start; the same for every key of a shape.
+struct RotLayout {
+    size_t scal, part, a_mean, b_mean, t_mean, ac, bc, y, slabs, m0, m1, m2, m3, m4, m5, m6, m7, total;
+    size_t slab_floats;
+};
+RotLayout rot_layout(int64_t n, int64_t p, int count) {
+    RotLayout L{};
     const size_t q = (size_t)(n < p ? n : p);
-    size_t b = 4096;
-    b += up256(sizeof(double) * 2 * 64 * p) + 3 * up256(sizeof(float) * p);
-    b += 3 * up256(sizeof(float) * n * p);                      // Ac, Bc, and the alpha-interpolated copy
-    b += up256(sizeof(float) * SLAB_FLOATS);
-    if (n >= p) b += 4 * up256(sizeof(float) * p * p);          // M -> R, its Newton-Schulz twin, G, b G + c G^2
-    else b += 3 * up256(sizeof(float) * q * p) + 5 * up256(sizeof(float) * q * q);   // Qb^T, Z, twin; G, b G + c G^2, P, x P2^T, D
-    return b;
+    size_t cursor = 0;
+    auto take = [&](size_t count_, size_t elem) { const size_t o = cursor; cursor = up256(cursor + count_ * elem); return o; };
+    auto fl = [&](size_t count_) { return take(count_, sizeof(float)); };
+    L.scal = take(8, sizeof(double));
+    L.part = take((size_t)2 * 64 * p, sizeof(double));
+    L.a_mean = fl(p); L.b_mean = fl(p); L.t_mean = fl(p);
+    L.ac = fl(n * p); L.bc = fl(n * p); L.y = fl(n * p);
+    // split-K slabs: what one launch may use is shared out over the keys of the batch, but a key always has room for
+    // two slabs of its largest product (the products are at most max(n, p) x p)
+    size_t slab = SLAB_FLOATS / (size_t)count;
+    const size_t floor_sq = 2 * q * q;
+    if (slab < floor_sq) slab = floor_sq;
+    if (slab > SLAB_FLOATS) slab = SLAB_FLOATS;
+    L.slab_floats = slab;
+    L.slabs = fl(slab);
+    if (n >= p) {                                               // M -> R, its Newton-Schulz twin, G, b G + c G^2
+        L.m0 = fl(p * p); L.m1 = fl(p * p); L.m2 = fl(p * p); L.m3 = fl(p * p);
+    } else {                                                    // Qb^T, Z, twin; G, b G + c G^2, P, x P2^T, D
+        L.m0 = fl(n * p); L.m1 = fl(n * p); L.m2 = fl(n * p);
+        L.m3 = fl(n * n); L.m4 = fl(n * n); L.m5 = fl(n * n); L.m6 = fl(n * n); L.m7 = fl(n * n);
+    }
+    L.total = up256(cursor);
+    return L;
+}
+// batched calls keep, ahead of the keys' workspaces, two words per key: `done` (polar convergence) and `not_close` (svd.py:46)
+size_t batch_header_bytes(int count) { return 2 * up256(sizeof(uint32_t) * (size_t)count); }
+
+// out = lerp(a, b, alpha) for the keys whose tensors are allclose in fp16 (svd.py:46-47); their flag word is recomputed
+__global__ __launch_bounds__(256) void rot_same_kernel(const void *a, const void *b, void *out, int in_dt, int out_dt, int64_t numel, float alpha,
+                                                       const uint32_t *not_close, uint32_t *flags, Batch bt) {
+    const int key = blockIdx.y;
+    if (not_close[key] != 0u) return;
+    const int64_t base = key_off(bt, key);
+    const float wm1 = alpha - 1.0f;
+    const bool small = __builtin_fabsf(alpha) < 0.5f;
+    bool bad_in = false, bad_out = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float x = ld_any(in_dt, a, base + i), y = ld_any(in_dt, b, base + i);
+        const float v = lerp_torch(x, y, alpha, wm1, small);
+        bad_in |= nonfinite_f32(x) | nonfinite_f32(y);
+        bad_out |= nonfinite_f32(v);
+        if (out_dt == MECHA_BF16) store1<MECHA_BF16>(out, base + i, v);
+        else if (out_dt == MECHA_F16) store1<MECHA_F16>(out, base + i, v);
+        else store1<MECHA_F32>(out, base + i, v);
+    }
+    if (flags != nullptr && (bad_in || bad_out)) atomicOr(flags + key, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
+}
+// the rotation's own output flag of such a key is void (its output was overwritten): clear it before rot_same_kernel runs
+__global__ __launch_bounds__(64) void rot_same_clear_kernel(const uint32_t *not_close, uint32_t *flags, int count) {
+    const int key = blockIdx.x * 64 + threadIdx.x;
+    if (key < count && not_close[key] == 0u) flags[key] &= ~(uint32_t)MECHA_FLAG_OUTPUT_NONFINITE;
+}
+
+struct RotCall {
+    const void *a, *b;
+    void *out;
+    const int64_t *offs;                    // device: element offset of every key inside a / b / out; nullptr = one key at 0
+    int count;
+    int64_t n, p;
+    int in_dt, out_dt;
+    float centralization;
+    int alignment;
+    float alpha;
+    const float *transform_in;              // one key only
+    float *transform_out;                   // one key only
+    void *workspace;
+    size_t workspace_bytes;
+    int *sweeps_out;
+    uint32_t *flags;                        // one word per key
+    bool allclose_check;                    // batched form: svd.py:46 is evaluated on the device
+    void *stream;
+};
+
+int rotate_run(const RotCall &c) {
+    const int64_t n = c.n, p = c.p;
+    const int count = c.count;
+    const RotLayout L = rot_layout(n, p, count);
+    const size_t header = c.offs != nullptr ? batch_header_bytes(count) : 0;
+    const size_t need = header + L.total * (size_t)count;
+    MECHA_REQUIRE(c.workspace != nullptr && c.workspace_bytes >= need && mecha_aligned16(c.workspace),
+                  "rotate workspace too small or unaligned: need %zu bytes, got %zu", need, c.workspace_bytes);
+    hipStream_t s = static_cast<hipStream_t>(c.stream);
+    char *ws0 = static_cast<char *>(c.workspace);
+    uint32_t *done = reinterpret_cast<uint32_t *>(ws0), *not_close = reinterpret_cast<uint32_t *>(ws0 + header / 2);
+    char *ws = ws0 + header;                                    // key 0's workspace
+    if (header) MECHA_CHECK_HIP(hipMemsetAsync(ws0, 0, header, s));
+    const Batch bt{count, count > 1 ? (int64_t)L.total : 0, c.offs, nullptr};
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    double *scal = reinterpret_cast<double *>(ws + L.scal), *part = reinterpret_cast<double *>(ws + L.part);
+    float *a_mean = F(L.a_mean), *b_mean = F(L.b_mean), *t_mean = F(L.t_mean), *ac = F(L.ac), *bc = F(L.bc), *y = F(L.y);
+    GemmCtx g{bt, F(L.slabs), L.slab_floats, s};
+    if (c.sweeps_out) *c.sweeps_out = 0;
+    // a single key without the header keeps its done word in the scal block (8 doubles: words 0-1 norms, the rest spare)
+    if (!header) done = reinterpret_cast<uint32_t *>(scal + 4);
+
+    const int chunks = (int)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+    hipLaunchKernelGGL(rot_colsum_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)chunks, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p,
+                       chunks, part, c.flags, bt);
+    hipLaunchKernelGGL(rot_means_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)count), dim3(256), 0, s, part, chunks, n, p, c.centralization,
+                       (float)c.alignment, a_mean, b_mean, t_mean, bt);
+    const int64_t total = n * p;
+    const int64_t cbw = (total + 255) / 256, cb_cap = count >= 64 ? 64 : 4096 / count;
+    const unsigned cb = (unsigned)(cbw < cb_cap ? cbw : cb_cap);
+    hipLaunchKernelGGL(rot_center_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac, bc, bt);
+    if (c.allclose_check)
+        hipLaunchKernelGGL(rot_allclose_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, total, not_close, bt);
+
+    const bool has_alpha = c.alpha != 0.0f;
+    const int alignment = c.alignment;
+    const float alpha = c.alpha;
+    const GemmEpilogue none{};
+    GemmEpilogue fin{};                                         // + lerp(a_mean, b_mean, alignment), cast, finite flag  (svd.py:85-86)
+    fin.col_bias = t_mean; fin.out = c.out; fin.out_dt = c.out_dt; fin.flags = c.flags;
+    int rc;
+    if (n >= p) {
+        float *R = F(L.m0), *twin = F(L.m1), *G = F(L.m2), *G2 = F(L.m3);
+        if (c.transform_in != nullptr) {
+            MECHA_CHECK_HIP(hipMemcpyAsync(R, c.transform_in, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
+        } else {
+            // M = Ac^T Bc:  M[i][j] = sum_r Ac[r][i] Bc[r][j];  R = U V^T = the orthogonal polar factor of M
+            gemm(Operand{ac, p, 1}, Operand{bc, p, 1}, R, p, p, n, none, g);
+            if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, done, c.sweeps_out, g, false, false)) != MECHA_OK) return rc;
+        }
+        if (c.transform_out != nullptr) MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, R, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
+        const float *src = ac;
+        if (has_alpha) {
+            // lerp(Ac, Bc R^T, alpha)  (svd.py:81-82; transform(b_2d, -1) = b_2d @ R.mH):  (Bc R^T)[r][i] = sum_j Bc[r][j] R[i][j]
+            GemmEpilogue e = alignment == 0 ? fin : none;
+            e.axpy = ac; e.axpy_a = 1.0f - alpha; e.axpy_b = alpha;
+            gemm(Operand{bc, 1, p}, Operand{R, 1, p}, y, n, p, p, e, g);
+            src = y;
+        }
+        // out[r][j] = sum_i src[r][i] R[i][j] + mean[j]   (alignment 1),  sum_i src[r][i] R[j][i] + mean[j]   (alignment -1)
+        if (alignment == 1) gemm(Operand{src, 1, p}, Operand{R, p, 1}, nullptr, n, p, p, fin, g);
+        else if (alignment == -1) gemm(Operand{src, 1, p}, Operand{R, 1, p}, nullptr, n, p, p, fin, g);
+    } else {
+        float *qbt = F(L.m0), *z = F(L.m1), *twin = F(L.m2);
+        float *G = F(L.m3), *G2 = F(L.m4), *P = F(L.m5), *xq = F(L.m6), *D = F(L.m7);
+        const size_t pitch = bt.ws_bytes ? (size_t)bt.ws_bytes : sizeof(float) * n * p;
+        if (c.transform_in != nullptr) {
+            MECHA_CHECK_HIP(hipMemcpyAsync(qbt, c.transform_in, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+            MECHA_CHECK_HIP(hipMemcpyAsync(z, c.transform_in + n * p, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+        } else {
+            // Qb^T = polar factor of Bc: orthonormal rows spanning the row space of Bc (= columns of b.mH)
+            MECHA_CHECK_HIP(hipMemcpy2DAsync(qbt, pitch, bc, pitch, sizeof(float) * n * p, (size_t)count, hipMemcpyDeviceToDevice, s));
+            // fully centred (the default): both wide-case matrices have the all-ones vector as their exact left null vector
+            const bool deflate = c.centralization == 1.0f;
+            if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true)) != MECHA_OK) return rc;
+            // T^T = Bc Qb =: P (n x n):  P[r][k] = sum_c Bc[r][c] Qb^T[k][c]
+            gemm(Operand{bc, 1, p}, Operand{qbt, 1, p}, P, n, n, p, none, g);
+            // N^T = P^T Ac (n x p):  N^T[k][i] = sum_r P[r][k] Ac[r][i];  N = U S W^T, Z := polar(N^T) = W U^T
+            gemm(Operand{P, n, 1}, Operand{ac, p, 1}, z, n, p, n, none, g);
+            if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true)) != MECHA_OK) return rc;
+        }
+        if (c.transform_out != nullptr) {
+            MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, qbt, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+            MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out + n * p, z, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+        }
+        // With V = Qb W (the reference's v) and U (its u):  U V^T = Z^T Qb^T,  V V^T = Qb Qb^T,  U U^T = Z^T Z,  V U^T = Qb Z.  So
+        //   transform(x, +1) = x - x V V^T + x U V^T = x + (x Z^T - x Qb) Qb^T      (svd.py:181)   -> low_rank(x, Z, Qb^T)
+        //   transform(x, -1) = x - x U U^T + x V U^T = x + (x Qb - x Z^T) Z         (svd.py:183)   -> low_rank(x, Qb^T, Z)
+        auto low_rank = [&](const float *x, const float *P1, const float *P2, float *C, GemmEpilogue e) {
+            gemm(Operand{x, 1, p}, Operand{P2, 1, p}, xq, n, n, p, none, g);                // xq[r][k] = sum_c x[r][c] P2[k][c]
+            GemmEpilogue minus_xq{};
+            minus_xq.minus = xq;
+            gemm(Operand{x, 1, p}, Operand{P1, 1, p}, D, n, n, p, minus_xq, g);             // D = x P1^T - x P2^T
+            e.plus = x;
+            gemm(Operand{D, 1, n}, Operand{P2, p, 1}, C, n, p, n, e, g);                    // C[r][c] = x[r][c] + sum_k D[r][k] P2[k][c]
+        };
+        const float *src = ac;
+        if (has_alpha) {
+            GemmEpilogue e = alignment == 0 ? fin : none;
+            e.mix = ac; e.mix_w0 = 1.0f - alpha; e.mix_w1 = alpha;                          // lerp(Ac, transform(Bc, -1), alpha)
+            low_rank(bc, qbt, z, y, e);
+            src = y;
+        }
+        if (alignment == 1) low_rank(src, z, qbt, nullptr, fin);
+        else if (alignment == -1) low_rank(src, qbt, z, nullptr, fin);
+    }
+    if (c.allclose_check) {
+        if (c.flags != nullptr)
+            hipLaunchKernelGGL(rot_same_clear_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s, not_close, c.flags, count);
+        hipLaunchKernelGGL(rot_same_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.out, c.in_dt, c.out_dt, total, alpha, not_close,
+                           c.flags, bt);
+    }
+    MECHA_CHECK_HIP(hipGetLastError());
+    return MECHA_OK;
 }
 
 }  // namespace
@@ -610,7 +935,14 @@ extern "C" {
 size_t mecha_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols) {
     if (n_rows < 1) n_rows = 1;
     if (n_cols < 1) n_cols = 1;
-    return rotate_workspace_bytes_impl(n_rows, n_cols);
+    return rot_layout(n_rows, n_cols, 1).total;
+}
+
+size_t mecha_batched_rotate_workspace_bytes(int64_t n_rows, int64_t n_cols, int n_keys) {
+    if (n_rows < 1) n_rows = 1;
+    if (n_cols < 1) n_cols = 1;
+    if (n_keys < 1) n_keys = 1;
+    return batch_header_bytes(n_keys) + rot_layout(n_rows, n_cols, n_keys).total * (size_t)n_keys;
 }
 
 int64_t mecha_rotate_transform_floats(int64_t n_rows, int64_t n_cols) {
@@ -626,99 +958,11 @@ int mecha_rotate_ex(const void *a, const void *b, void *out, int64_t n, int64_t 
     MECHA_REQUIRE(mecha_valid_dtype(in_dtype) && mecha_valid_dtype(out_dtype), "unknown dtype code");
     MECHA_REQUIRE(alignment >= -1 && alignment <= 1, "rotate: alignment must be -1, 0 or 1 (fractional powers are outside this path), got %d", alignment);
     MECHA_REQUIRE(alpha == alpha, "rotate: alpha is NaN");
-    const bool has_alpha = alpha != 0.0f;
-    MECHA_REQUIRE(alignment != 0 || has_alpha, "rotate: alignment == 0 with alpha == 0 is the identity (svd.py:39-40); return a instead");
-    const size_t need = rotate_workspace_bytes_impl(n, p);
-    MECHA_REQUIRE(workspace != nullptr && workspace_bytes >= need && mecha_aligned16(workspace),
-                  "rotate workspace too small or unaligned: need %zu bytes, got %zu", need, workspace_bytes);
+    MECHA_REQUIRE(alignment != 0 || alpha != 0.0f, "rotate: alignment == 0 with alpha == 0 is the identity (svd.py:39-40); return a instead");
     MECHA_REQUIRE(transform_in == nullptr || mecha_aligned16(transform_in), "rotate: transform_in must be 16-byte aligned");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    Bump ws{static_cast<char *>(workspace), 0};
-    const int chunks = (int)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
-    double *scal = ws.take<double>(8);
-    double *part = ws.take<double>((size_t)2 * 64 * p);
-    float *a_mean = ws.take<float>(p), *b_mean = ws.take<float>(p), *t_mean = ws.take<float>(p);
-    float *ac = ws.take<float>(n * p), *bc = ws.take<float>(n * p), *y = ws.take<float>(n * p);
-    float *slabs = ws.take<float>(SLAB_FLOATS);
-    if (sweeps_out) *sweeps_out = 0;
-
-    hipLaunchKernelGGL(rot_colsum_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)chunks), dim3(256), 0, s, a, b, in_dtype, n, p, chunks, part, flags);
-    hipLaunchKernelGGL(rot_means_kernel, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, s, part, chunks, n, p, centralization,
-                       (float)alignment, a_mean, b_mean, t_mean);
-    const int64_t total = n * p;
-    const unsigned cb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(rot_center_kernel, dim3(cb), dim3(256), 0, s, a, b, in_dtype, n, p, a_mean, b_mean, ac, bc);
-
-    const GemmEpilogue none{};
-    GemmEpilogue fin{};                                         // + lerp(a_mean, b_mean, alignment), cast, finite flag  (svd.py:85-86)
-    fin.col_bias = t_mean; fin.out = out; fin.out_dt = out_dtype; fin.flags = flags;
-    int rc;
-    if (n >= p) {
-        float *R = ws.take<float>(p * p), *twin = ws.take<float>(p * p), *G = ws.take<float>(p * p), *G2 = ws.take<float>(p * p);
-        if (transform_in != nullptr) {
-            MECHA_CHECK_HIP(hipMemcpyAsync(R, transform_in, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
-        } else {
-            // M = Ac^T Bc:  M[i][j] = sum_r Ac[r][i] Bc[r][j];  R = U V^T = the orthogonal polar factor of M
-            gemm(Operand{ac, p, 1}, Operand{bc, p, 1}, R, p, p, n, slabs, none, s);
-            if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, slabs, sweeps_out, s)) != MECHA_OK) return rc;
-        }
-        if (transform_out != nullptr) MECHA_CHECK_HIP(hipMemcpyAsync(transform_out, R, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
-        const float *src = ac;
-        if (has_alpha) {
-            // lerp(Ac, Bc R^T, alpha)  (svd.py:81-82; transform(b_2d, -1) = b_2d @ R.mH):  (Bc R^T)[r][i] = sum_j Bc[r][j] R[i][j]
-            GemmEpilogue e = alignment == 0 ? fin : none;
-            e.axpy = ac; e.axpy_a = 1.0f - alpha; e.axpy_b = alpha;
-            gemm(Operand{bc, 1, p}, Operand{R, 1, p}, y, n, p, p, slabs, e, s);
-            src = y;
-        }
-        // out[r][j] = sum_i src[r][i] R[i][j] + mean[j]   (alignment 1),  sum_i src[r][i] R[j][i] + mean[j]   (alignment -1)
-        if (alignment == 1) gemm(Operand{src, 1, p}, Operand{R, p, 1}, nullptr, n, p, p, slabs, fin, s);
-        else if (alignment == -1) gemm(Operand{src, 1, p}, Operand{R, 1, p}, nullptr, n, p, p, slabs, fin, s);
-    } else {
-        float *qbt = ws.take<float>(n * p), *z = ws.take<float>(n * p), *twin = ws.take<float>(n * p);
-        float *G = ws.take<float>(n * n), *G2 = ws.take<float>(n * n), *P = ws.take<float>(n * n), *xq = ws.take<float>(n * n), *D = ws.take<float>(n * n);
-        if (transform_in != nullptr) {
-            MECHA_CHECK_HIP(hipMemcpyAsync(qbt, transform_in, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-            MECHA_CHECK_HIP(hipMemcpyAsync(z, transform_in + n * p, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-        } else {
-            // Qb^T = polar factor of Bc: orthonormal rows spanning the row space of Bc (= columns of b.mH)
-            MECHA_CHECK_HIP(hipMemcpyAsync(qbt, bc, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-            // fully centred (the default): both wide-case matrices have the all-ones vector as their exact left null vector
-            const bool deflate = centralization == 1.0f;
-            if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, slabs, sweeps_out, s, deflate)) != MECHA_OK) return rc;
-            // T^T = Bc Qb =: P (n x n):  P[r][k] = sum_c Bc[r][c] Qb^T[k][c]
-            gemm(Operand{bc, 1, p}, Operand{qbt, 1, p}, P, n, n, p, slabs, none, s);
-            // N^T = P^T Ac (n x p):  N^T[k][i] = sum_r P[r][k] Ac[r][i];  N = U S W^T, Z := polar(N^T) = W U^T
-            gemm(Operand{P, n, 1}, Operand{ac, p, 1}, z, n, p, n, slabs, none, s);
-            if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, slabs, sweeps_out, s, deflate)) != MECHA_OK) return rc;
-        }
-        if (transform_out != nullptr) {
-            MECHA_CHECK_HIP(hipMemcpyAsync(transform_out, qbt, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-            MECHA_CHECK_HIP(hipMemcpyAsync(transform_out + n * p, z, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
-        }
-        // With V = Qb W (the reference's v) and U (its u):  U V^T = Z^T Qb^T,  V V^T = Qb Qb^T,  U U^T = Z^T Z,  V U^T = Qb Z.  So
-        //   transform(x, +1) = x - x V V^T + x U V^T = x + (x Z^T - x Qb) Qb^T      (svd.py:181)   -> low_rank(x, Z, Qb^T)
-        //   transform(x, -1) = x - x U U^T + x V U^T = x + (x Qb - x Z^T) Z         (svd.py:183)   -> low_rank(x, Qb^T, Z)
-        auto low_rank = [&](const float *x, const float *P1, const float *P2, float *C, GemmEpilogue e) {
-            gemm(Operand{x, 1, p}, Operand{P2, 1, p}, xq, n, n, p, slabs, none, s);         // xq[r][k] = sum_c x[r][c] P2[k][c]
-            GemmEpilogue minus_xq{};
-            minus_xq.minus = xq;
-            gemm(Operand{x, 1, p}, Operand{P1, 1, p}, D, n, n, p, slabs, minus_xq, s);      // D = x P1^T - x P2^T
-            e.plus = x;
-            gemm(Operand{D, 1, n}, Operand{P2, p, 1}, C, n, p, n, slabs, e, s);             // C[r][c] = x[r][c] + sum_k D[r][k] P2[k][c]
-        };
-        const float *src = ac;
-        if (has_alpha) {
-            GemmEpilogue e = alignment == 0 ? fin : none;
-            e.mix = ac; e.mix_w0 = 1.0f - alpha; e.mix_w1 = alpha;                          // lerp(Ac, transform(Bc, -1), alpha)
-            low_rank(bc, qbt, z, y, e);
-            src = y;
-        }
-        if (alignment == 1) low_rank(src, z, qbt, nullptr, fin);
-        else if (alignment == -1) low_rank(src, qbt, z, nullptr, fin);
-    }
-    MECHA_CHECK_HIP(hipGetLastError());
-    return MECHA_OK;
+    RotCall c{a, b, out, nullptr, 1, n, p, in_dtype, out_dtype, centralization, alignment, alpha, transform_in, transform_out, workspace,
+              workspace_bytes, sweeps_out, flags, false, stream};
+    return rotate_run(c);
 }
 
 int mecha_rotate(const void *a, const void *b, void *out, int64_t n, int64_t p, int in_dtype, int out_dtype, float centralization,
@@ -727,13 +971,31 @@ int mecha_rotate(const void *a, const void *b, void *out, int64_t n, int64_t p, 
                            sweeps_out, flags, stream);
 }
 
+// Every key of one 2-D shape in one launch sequence (DESIGN.md "rotate": batches).  The keys lie in the per-model arenas at
+// key_offsets[i] elements (DEVICE table, offsets multiples of 8 elements); flags: one word per key.  svd.py:46's
+// allclose(a.half(), b.half()) early-out is evaluated per key on the device: such keys get lerp(a, b, alpha).
+int mecha_batched_rotate(const void *a_arena, const void *b_arena, void *out_arena, const int64_t *key_offsets, int n_keys, int64_t n,
+                         int64_t p, int in_dtype, int out_dtype, float centralization, int alignment, float alpha, void *workspace,
+                         size_t workspace_bytes, uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(a_arena != nullptr && b_arena != nullptr && out_arena != nullptr && key_offsets != nullptr, "NULL pointer");
+    MECHA_REQUIRE(n_keys >= 1 && n_keys <= 16384, "batched rotate takes 1..16384 keys per call (got %d)", n_keys);
+    MECHA_REQUIRE(n >= 1 && p >= 1, "rotate needs a non-empty 2-D key (got %lld x %lld)", (long long)n, (long long)p);
+    MECHA_REQUIRE(mecha_valid_dtype(in_dtype) && mecha_valid_dtype(out_dtype), "unknown dtype code");
+    MECHA_REQUIRE(alignment >= -1 && alignment <= 1, "rotate: alignment must be -1, 0 or 1 (fractional powers are outside this path), got %d", alignment);
+    MECHA_REQUIRE(alpha == alpha, "rotate: alpha is NaN");
+    MECHA_REQUIRE(alignment != 0 || alpha != 0.0f, "rotate: alignment == 0 with alpha == 0 is the identity (svd.py:39-40); return a instead");
+    RotCall c{a_arena, b_arena, out_arena, key_offsets, n_keys, n, p, in_dtype, out_dtype, centralization, alignment, alpha, nullptr, nullptr,
+              workspace, workspace_bytes, nullptr, flags, true, stream};
+    return rotate_run(c);
+}
+
 // torch.allclose(a.half(), b.half()) of svd.py:46.  ORs 1 into *not_close (device word, zeroed by the caller) if any element differs.
 int mecha_allclose_half(const void *a, const void *b, int64_t numel, int in_dtype, uint32_t *not_close, void *stream) {
     MECHA_REQUIRE(numel >= 0 && mecha_valid_dtype(in_dtype) && not_close != nullptr, "bad arguments");
     if (numel == 0) return MECHA_OK;
     MECHA_REQUIRE(a != nullptr && b != nullptr, "NULL tensor pointer");
     const unsigned blocks = (unsigned)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
-    hipLaunchKernelGGL(rot_allclose_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, in_dtype, numel, not_close);
+    hipLaunchKernelGGL(rot_allclose_kernel, dim3(blocks, 1), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, in_dtype, numel, not_close, ONE_KEY);
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;
 }

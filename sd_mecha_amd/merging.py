@@ -50,10 +50,11 @@ log = logging.getLogger("sd_mecha_amd")
 @dataclass
 class FusedPlan:
     """A recipe the batched kernels cover end to end."""
-    kind: str                                   # "wsum" | "navg" | "ties"
+    kind: str                                   # "wsum" | "navg" | "ties" | "lora" | "rotate"
     models: List[ModelRecipeNode]               # inputs in kernel order (ties: base first)
     params: Dict[str, Any] = field(default_factory=dict)
     fallback: Optional[ModelRecipeNode] = None  # `| model`: value of a key whose merge was skipped
+    node: Optional[MergeRecipeNode] = None      # the merge node the plan stands for (merge(cache=...) is keyed by it)
 
 
 def _scalar(node: RecipeNode, default=None):
@@ -113,6 +114,19 @@ def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
                 models.append(d.args[0])
             if k is not None and models and len(models) < _lib.MAX_MODELS and not math.isclose(alpha, 0.0):
                 return FusedPlan("ties", [base] + models, {"k": k, "alpha": alpha, "vote_sgn": vote}, fallback)
+    if ident == "rotate":
+        # svd.py:10-86 on two models with whole-number alignment and scalar alpha: keys of equal 2-D shape are rotated together
+        # (one launch sequence per shape group); the degenerate settings that return an input untouched (svd.py:37-42) and
+        # fractional alignment stay on the per-key path
+        b = _bound(recipe)
+        alignment = _scalar(b.get("alignment"), 1.0) if "alignment" in b else 1.0
+        alpha = _scalar(b.get("alpha"), 0.0) if "alpha" in b else 0.0
+        cz = _scalar(b.get("centralization"), 1.0) if "centralization" in b else 1.0
+        if (isinstance(b.get("a"), ModelRecipeNode) and isinstance(b.get("b"), ModelRecipeNode) and None not in (alignment, alpha, cz)
+                and any(math.isclose(alignment, w) for w in (-1.0, 0.0, 1.0))
+                and not (math.isclose(alignment, 0.0) and math.isclose(alpha, 0.0))
+                and not (math.isclose(alignment, 1.0) and math.isclose(alpha, 1.0))):
+            return FusedPlan("rotate", [b["a"], b["b"]], {"alignment": int(round(alignment)), "alpha": alpha, "centralization": cz}, fallback, recipe)
     if ident == "add_difference_ties":
         k = _scalar(recipe.kwargs.get("k"), 1.0) if "k" in recipe.kwargs else 1.0          # wrappers.py:70-75
         alpha = _scalar(recipe.kwargs.get("alpha"), 1.0) if "alpha" in recipe.kwargs else 1.0
@@ -330,8 +344,10 @@ class HipBackend:
         return torch.cuda.Stream(device=self.device)
 
     def run_fused(self, plan: FusedPlan, arenas: Sequence[torch.Tensor], out: torch.Tensor, layout: ArenaLayout,
-                  segs_dev: torch.Tensor, segs_host, flags: torch.Tensor, workspace: Optional[torch.Tensor]) -> None:
+                  segs_dev: torch.Tensor, segs_host, flags: torch.Tensor, workspace: Optional[torch.Tensor], shapes=None) -> None:
         import ctypes
+        if plan.kind == "rotate":
+            return self._run_rotate(plan, arenas, out, layout, flags, shapes)
         L = self.lib
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         in_dt, out_dt, n = _DT_CODE[arenas[0].dtype], _DT_CODE[out.dtype], len(layout.keys)
@@ -349,6 +365,57 @@ class HipBackend:
         else:
             raise ValueError(plan.kind)
         _lib.check(st, f"batched {plan.kind}")
+
+    # most workspace one batched rotate call may take; a shape group that needs more is cut into several calls
+    ROTATE_WORKSPACE_BYTES = 24 << 30
+
+    def _run_rotate(self, plan: FusedPlan, arenas, out, layout: ArenaLayout, flags: torch.Tensor, shapes) -> None:
+        """rotate over a wave (svd.py:10-86 per key): keys of <= 1 dimension are lerp(a, b, alpha) (svd.py:46-47) in one batched
+        launch over their own segment table; the others are grouped by their 2-D shape (svd.py:49-53) and every group runs
+        as one batched launch sequence (mecha_batched_rotate)."""
+        import ctypes
+        L = self.lib
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        in_dt, out_dt = _DT_CODE[arenas[0].dtype], _DT_CODE[out.dtype]
+        alpha, alignment, cz = plan.params["alpha"], plan.params["alignment"], plan.params["centralization"]
+        flat, groups = [], {}
+        for i, shape in enumerate(shapes):
+            if len(shape) <= 1:
+                flat.append(i)
+            else:
+                groups.setdefault(mm.rotate_shape_2d(shape), []).append(i)
+        # one index tensor for the whole wave: [flat keys..., group 0 keys..., group 1 keys...]; per-call flag words are
+        # gathered back into the wave's order at the end
+        order = flat + [i for idx in groups.values() for i in idx]
+        offs_all = torch.tensor([layout.offsets[i] for i in order], dtype=torch.int64).to(self.device)
+        fl_all = torch.zeros(max(len(order), 1), dtype=torch.int32, device=self.device)
+        pos = 0
+        if flat:
+            segs = torch.tensor([[layout.offsets[i], layout.numels[i]] for i in flat], dtype=torch.int64).to(self.device)
+            _lib.check(L.mecha_batched_weighted_sum(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(), segs.data_ptr(), len(flat),
+                                                    layout.total_elems, in_dt, out_dt, alpha, fl_all.data_ptr(), stream), "batched lerp (rotate, ndim <= 1)")
+            pos = len(flat)
+        for (n, p), idx in groups.items():
+            per_key = int(L.mecha_batched_rotate_workspace_bytes(n, p, 1))
+            chunk = max(1, min(len(idx), self.ROTATE_WORKSPACE_BYTES // max(per_key, 1)))
+            for c0 in range(0, len(idx), chunk):
+                cnt = min(chunk, len(idx) - c0)
+                nbytes = int(L.mecha_batched_rotate_workspace_bytes(n, p, cnt))
+                ws = self._rotate_ws(nbytes)
+                _lib.check(L.mecha_batched_rotate(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(),
+                                                  offs_all[pos + c0:].data_ptr(), cnt, n, p, in_dt, out_dt, float(cz), int(alignment), float(alpha),
+                                                  ws.data_ptr(), ws.numel(), fl_all[pos + c0:].data_ptr(), stream), "mecha_batched_rotate")
+            pos += len(idx)
+        if order:
+            flags.index_copy_(0, torch.tensor(order, dtype=torch.int64).to(self.device), fl_all[:len(order)])
+
+    def _rotate_ws(self, nbytes: int) -> torch.Tensor:
+        """One growing workspace per backend: the calls of a wave run one after the other on the compute stream."""
+        ws = getattr(self, "_rot_ws", None)
+        if ws is None or ws.numel() < nbytes:
+            self._rot_ws = None
+            ws = self._rot_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
 
     def run_lora(self, entries, base: torch.Tensor, out: torch.Tensor, flags: torch.Tensor) -> None:
         """Every key of a wave in one launch; `entries` as _LoraStore.entries returns them, `flags` one word per wave key."""
@@ -458,6 +525,8 @@ def merge(
     readers = {id(m): InSafetensorsDict(m.path) for m in models}
     try:
         plan = fuse(recipe)
+        if plan is not None and plan.kind == "rotate" and cache and any(n is plan.node for n in cache):
+            plan = None                                                      # svd.py:55-79: the factor cache lives on the per-key path
         # LoRA files name their tensors after the base keys (lora_<stem>.lora_up.weight ...): they take no part in config inference
         aux = _lora_file_nodes(recipe)
         merge_inputs = [m for m in models if id(m) not in aux]
@@ -701,7 +770,8 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
                 backend.run_lora(entries, bs["d_in"][0][:L.total_elems], bs["d_out"][:L.total_elems], flags)
             else:
                 bs["skip"] = ()
-                backend.run_fused(plan, [a[:L.total_elems] for a in bs["d_in"]], bs["d_out"][:L.total_elems], L, segs_dev, segs_host, flags, ws)
+                backend.run_fused(plan, [a[:L.total_elems] for a in bs["d_in"]], bs["d_out"][:L.total_elems], L, segs_dev, segs_host, flags, ws,
+                                  shapes=[tuple(header[k].shape) for k in L.keys])
             bs["flags"], bs["ws"], bs["segs_dev"] = flags, ws, segs_dev
             if is_cuda:
                 bs["ev_comp"] = torch.cuda.Event()
@@ -808,7 +878,7 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
                 entries, skip = lora_store.entries(L, header)
                 backend.run_lora(entries, big_in[0], big_out, flags)
             else:
-                backend.run_fused(plan, big_in, big_out, L, segs_dev, segs_host, flags, ws)
+                backend.run_fused(plan, big_in, big_out, L, segs_dev, segs_host, flags, ws, shapes=[tuple(meta.shape)])
             fl = int(flags.cpu()[0])                                   # waits for the kernels
         for bs in sets:
             bs.pop("ev_piece", None)

@@ -113,7 +113,7 @@ class OracleBackend:
     def workspace_bytes(self, plan, layout):
         return 0
 
-    def run_fused(self, plan, arenas, out, layout, segs_dev, segs_host, flags, workspace):
+    def run_fused(self, plan, arenas, out, layout, segs_dev, segs_host, flags, workspace, shapes=None):
         in_name, out_name = _NAME[arenas[0].dtype], _NAME[out.dtype]
         a_bits = [_bits(a) for a in arenas]
         o_bits = _bits(out)
@@ -132,6 +132,10 @@ class OracleBackend:
                 res = O.weighted_sum(f32[0], f32[1], plan.params["alpha"])
             elif plan.kind == "navg":
                 res = O.n_average(f32)
+            elif plan.kind == "rotate":
+                res = O.rotate(f32[0].reshape(shapes[i]), f32[1].reshape(shapes[i]), alignment=float(plan.params["alignment"]),
+                               alpha=plan.params["alpha"], centralization=plan.params["centralization"])
+                res = np.ascontiguousarray(res, dtype=np.float32).reshape(-1)
             else:
                 res = O.add_difference_ties(f32[0], f32[1:], k=plan.params["k"], alpha=plan.params["alpha"], vote_sgn=plan.params["vote_sgn"])
             if not O.all_finite(res):

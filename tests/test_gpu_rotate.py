@@ -75,7 +75,7 @@ def test_rotate_vs_oracle(oracle, shape, cz):
     got, sweeps = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=cz, return_sweeps=True)
     rel = rotate_rel_error(oracle, a, b, got.cpu().numpy(), want, cz)
     assert rel <= 1e-3, (shape, cz, rel, sweeps)
-    assert sweeps in (14, 28)          # polar iteration steps: 14 per solve, two solves for wide keys
+    assert sweeps in (14, 40)          # polar steps enqueued: 14 for the solve of a tall key, 2 x (6 + 14) for a wide key's two
     # the transform is orthogonal on the rotated subspace: norms of centred rows are preserved (tall / square keys)
     n, p = oracle.rotate_shape_2d(shape)
     if n >= p and n > p + 1:
@@ -157,3 +157,73 @@ def test_rotate_recipe_with_cache(oracle, tmp_path):
             assert rel <= 1e-3, (k, alpha, rel)
     assert set(cache) == {"w.tall", "w.wide", "w.conv"}          # 1-D keys take the lerp early-out before the cache (svd.py:46-47)
     assert all(v["transform"].dtype == torch.float16 for v in cache.values())
+
+
+def _write_pair(tmp_path, tensors_a, tensors_b):
+    import safetensors.torch
+    for name, sd in (("a", tensors_a), ("b", tensors_b)):
+        safetensors.torch.save_file({k: torch.from_numpy(v).to(torch.bfloat16) for k, v in sd.items()}, str(tmp_path / f"{name}.safetensors"))
+    return tmp_path / "a.safetensors", tmp_path / "b.safetensors"
+
+
+@pytest.mark.parametrize("alignment,alpha,cz", [(1.0, 0.0, 1.0), (1.0, 0.3, 1.0), (-1.0, 0.0, 0.0), (0.0, 0.6, 1.0)])
+def test_batched_rotate_through_merge(oracle, tmp_path, alignment, alpha, cz):
+    """merge(rotate(a, b)) takes the batched plan: keys grouped by 2-D shape, one launch sequence per group
+    (mecha_batched_rotate), the svd.py:46-47 early-outs evaluated on the device.  Every key against the oracle."""
+    import sd_mecha_amd as amd
+    from sd_mecha_amd import merging
+    rng = np.random.default_rng(2024)
+    shapes = {"t0": (320, 96), "t1": (320, 96), "t2": (320, 96), "sq0": (256, 256), "sq1": (256, 256), "w0": (96, 512), "w1": (96, 512),
+              "w2": (96, 512), "c0": (32, 16, 3, 3), "c1": (32, 16, 3, 3), "bias": (320,), "same": (64, 48), "big": (640, 384)}
+    bf = lambda x: oracle.to_f32(oracle.from_f32(x.astype(np.float32), "bfloat16"), "bfloat16")      # noqa: E731
+    ta = {k: bf(rng.normal(0, 0.02, size=s)) for k, s in shapes.items()}
+    tb = {k: bf(rng.normal(0, 0.02, size=s)) for k, s in shapes.items()}
+    tb["same"] = ta["same"].copy()                                  # allclose(a.half(), b.half()) -> lerp (svd.py:46-47)
+    pa, pb = _write_pair(tmp_path, ta, tb)
+    node = amd.rotate(amd.model(pa), amd.model(pb), alignment=alignment, alpha=alpha, centralization=cz)
+    res = amd.merge(node, output_dtype=torch.float32, merge_device="cuda")
+    assert merging.last_stats["fused_keys"] == len(shapes) and merging.last_stats["generic_keys"] == 0
+    for k, shape in shapes.items():
+        want = oracle.rotate(ta[k], tb[k], alignment=alignment, alpha=alpha, centralization=cz)
+        got = res[k].cpu().numpy()
+        if len(shape) <= 1 or k == "same":
+            assert np.array_equal(got, np.asarray(want, dtype=np.float32).reshape(shape)), k
+            continue
+        if rotate_case_undetermined(oracle, shape, alignment, alpha, cz):
+            continue
+        rel = rotate_rel_error(oracle, ta[k], tb[k], got, want, cz, alignment, alpha)
+        assert rel <= 1e-3, (k, alignment, alpha, cz, rel)
+    # the batched and the per-key entry point agree (same kernels; the wide keys' early exit is the only difference)
+    per_key = amd.merge(node, output_dtype=torch.float32, merge_device="cuda", cache={node: node.merge_method.create_cache()})
+    assert merging.last_stats["fused_keys"] == 0
+    for k in shapes:
+        d = np.linalg.norm(res[k].cpu().numpy().astype(np.float64) - per_key[k].cpu().numpy()) / max(np.linalg.norm(per_key[k].cpu().numpy()), 1e-30)
+        assert d <= 2e-3, (k, d)
+
+
+@pytest.mark.parametrize("polar_mode", ["", "both", "long"])
+def test_batched_rotate_ill_conditioned_wide_keys(oracle, tmp_path, monkeypatch, polar_mode):
+    """Wide keys whose b has singular values over three decades fail the optimistic 6-step polar schedule's convergence
+    test and go on through the 14-step one, in the same batch as well-conditioned keys that leave after 6 steps."""
+    import sd_mecha_amd as amd
+    if polar_mode:                                                  # "both": every key falls through; "long": no short schedule
+        monkeypatch.setenv("MECHA_ROT_POLAR", polar_mode)
+    rng = np.random.default_rng(7)
+    n, p = 64, 256
+    ta, tb = {}, {}
+    for i in range(4):
+        u, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        v, _ = np.linalg.qr(rng.normal(size=(p, n)))
+        sv = np.logspace(0, -3 if i % 2 else -0.3, n)              # odd keys: condition number 1e3
+        ta[f"k{i}"] = rng.normal(0, 0.02, size=(n, p)).astype(np.float32)
+        tb[f"k{i}"] = ((u * sv) @ v.T * 0.5).astype(np.float32)
+    bf = lambda x: oracle.to_f32(oracle.from_f32(x, "bfloat16"), "bfloat16")      # noqa: E731
+    ta = {k: bf(v) for k, v in ta.items()}
+    tb = {k: bf(v) for k, v in tb.items()}
+    pa, pb = _write_pair(tmp_path, ta, tb)
+    res = amd.merge(amd.rotate(amd.model(pa), amd.model(pb), alignment=1.0, alpha=0.0, centralization=0.0), output_dtype=torch.float32,
+                    merge_device="cuda")
+    for k in ta:
+        want = oracle.rotate(ta[k], tb[k], alignment=1.0, alpha=0.0, centralization=0.0)
+        rel = rotate_rel_error(oracle, ta[k], tb[k], res[k].cpu().numpy(), want, 0.0)
+        assert rel <= 1e-3, (k, rel)

@@ -273,3 +273,27 @@ def test_two_ranks_fill_one_file(toy_models, tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_rank_main, args=(2, [str(p) for p in toy_models], str(out), port), nprocs=2, join=True)
     check_against_reference(safetensors.torch.load_file(str(out)), "navg4")
+
+
+def test_rotate_recipe_takes_the_batched_plan(toy_models, tmp_path):
+    """rotate(model, model) is a fused plan: the scheduler stages both models' arenas and hands the backend every key with
+    its shape (the HIP backend groups them by 2-D shape, svd.py:49-53).  Same values as the per-key path; with cache= the
+    plan steps aside (svd.py:55-79 is a per-key feature)."""
+    import sd_mecha_amd as amd
+    from sd_mecha_amd import merging
+    from oracle_backend import OracleBackend
+    from oracle import oracle as O
+    a, b = amd.model(toy_models[0]), amd.model(toy_models[1])
+    node = amd.rotate(a, b, alignment=1.0, alpha=0.25)
+    plan = merging.fuse(node)
+    assert plan is not None and plan.kind == "rotate" and plan.params == {"alignment": 1, "alpha": 0.25, "centralization": 1.0}
+    assert merging.fuse(amd.rotate(a, b, alignment=0.0, alpha=0.0)) is None          # returns `a` untouched (svd.py:39-40)
+    assert merging.fuse(amd.rotate(a, b, alignment=0.5, alpha=0.0)) is None          # fractional alignment
+    res = amd.merge(node, output_dtype=torch.float32, backend=OracleBackend())
+    assert merging.last_stats["fused_keys"] == 4 and merging.last_stats["generic_keys"] == 0
+    g = load_golden("e2e")
+    for k, shape in SHAPES.items():
+        x = O.to_f32(g[f"e_m0_{k}"], "bfloat16").reshape(shape)
+        y = O.to_f32(g[f"e_m1_{k}"], "bfloat16").reshape(shape)
+        want = O.rotate(x, y, alignment=1.0, alpha=0.25, centralization=1.0)
+        assert np.allclose(res[k].numpy(), want, rtol=0, atol=1e-6 * max(1.0, float(np.abs(want).max()))), k
