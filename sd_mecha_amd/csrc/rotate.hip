@@ -268,10 +268,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, float *
 constexpr int GK2 = 16;
 constexpr int GP2 = 132;               // LDS row pitch in floats (528 B: 16-byte aligned rows, rows 4 banks apart)
 
+enum : int { LAYOUT_M = 0, LAYOUT_K = 1, LAYOUT_ANY = 2 };     // which direction of an operand is contiguous in memory (compiled in)
+template <int LAYOUT>
 __device__ __forceinline__ TileRegs tile_load128(const Operand &op, int64_t m0, int64_t M, int64_t k0, int64_t k_end) {
     TileRegs t;
     const int tid = threadIdx.x;
-    if (op.ms == 1) {                  // m-contiguous: thread = (k = tid / 16, 4 consecutive m at 4 * (tid % 16) [+64])
+    if constexpr (LAYOUT == LAYOUT_M) { // m-contiguous: thread = (k = tid / 16, 4 consecutive m at 4 * (tid % 16) [+64])
         const int64_t k = k0 + (tid >> 4);
         const bool vec_ok = ((op.ks & 3) == 0) && ((reinterpret_cast<uintptr_t>(op.p) & 15u) == 0);
 #pragma unroll
@@ -283,7 +285,7 @@ __device__ __forceinline__ TileRegs tile_load128(const Operand &op, int64_t m0, 
                 for (int j = 0; j < 4; j++) t.v[h][j] = (k < k_end && m + j < M) ? op.p[k * op.ks + m + j] : 0.0f;
             }
         }
-    } else if (op.ks == 1) {           // k-contiguous: thread = (m = tid / 4 [+64], 4 consecutive k at 4 * (tid % 4)): 4 lanes per row
+    } else if constexpr (LAYOUT == LAYOUT_K) {   // k-contiguous: thread = (m = tid / 4 [+64], 4 consecutive k at 4 * (tid % 4)): 4 lanes per row
         const int64_t k = k0 + 4 * (tid & 3);
         const bool vec_ok = ((op.ms & 3) == 0) && ((k0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(op.p) & 15u) == 0);
 #pragma unroll
@@ -305,12 +307,13 @@ __device__ __forceinline__ TileRegs tile_load128(const Operand &op, int64_t m0, 
     }
     return t;
 }
-__device__ __forceinline__ void tile_store128(const Operand &op, const TileRegs &t, float *lds) {
+template <int LAYOUT>
+__device__ __forceinline__ void tile_store128(const TileRegs &t, float *lds) {
     const int tid = threadIdx.x;
-    if (op.ms == 1) {
+    if constexpr (LAYOUT == LAYOUT_M) {
 #pragma unroll
         for (int h = 0; h < 2; h++) *reinterpret_cast<f32x4 *>(&lds[(tid >> 4) * GP2 + (tid & 15) * 4 + 64 * h]) = t.v[h];
-    } else if (op.ks == 1) {
+    } else if constexpr (LAYOUT == LAYOUT_K) {
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
@@ -324,10 +327,16 @@ __device__ __forceinline__ void tile_store128(const Operand &op, const TileRegs 
     }
 }
 
-__global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab, int n_slabs, Batch bt,
-                                                      GemmEpilogue e) {
+// symmetric: A and B are the same operand (C = X X^T, or G G of a symmetric G) and the epilogue is at most the axpy of a
+// symmetric matrix.  Only the tiles on and above the diagonal are computed; a tile above it is also stored transposed
+// (every lane holds 4 consecutive rows of one column = 16 contiguous bytes of the transposed tile).  The result is symmetric
+// bit for bit, as the full product was (the same products in the same order on both sides of the diagonal).
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 3) void gemm128_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab, int n_slabs, Batch bt,
+                                                      GemmEpilogue e, int symmetric) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][GK2 * GP2];     // [buffer][A | B]
     const int key = blockIdx.z / n_slabs, slab = blockIdx.z - key * n_slabs;
+    if (symmetric && blockIdx.x < blockIdx.y) return;
     if (bt.skip != nullptr && bt.skip[key] != 0u) return;
     A.p = key_ptr(A.p, bt, key); B.p = key_ptr(B.p, bt, key); C = key_ptr(C, bt, key);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -346,14 +355,14 @@ __global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, floa
     // software pipeline: the next chunk's global loads are in flight while the MFMAs consume the current LDS buffer.  (Two
     // chunks of register prefetch were tried: 221 VGPRs, one block per CU, 74 -> 112 us per launch on the SDXL mix.  The kernel
     // is bound by the latency of the operand loads; more blocks per CU hide it better than a deeper pipeline in registers.)
-    TileRegs ra = tile_load128(A, bm0, M, k_begin, k_end), rb = tile_load128(B, bn0, N, k_begin, k_end);
-    tile_store128(A, ra, lds[0][0]);
-    tile_store128(B, rb, lds[0][1]);
+    TileRegs ra = tile_load128<LA>(A, bm0, M, k_begin, k_end), rb = tile_load128<LB>(B, bn0, N, k_begin, k_end);
+    tile_store128<LA>(ra, lds[0][0]);
+    tile_store128<LB>(rb, lds[0][1]);
     __syncthreads();
     int buf = 0;
     for (int64_t k = k_begin; k < k_end; k += GK2) {
         const bool more = k + GK2 < k_end;
-        if (more) { ra = tile_load128(A, bm0, M, k + GK2, k_end); rb = tile_load128(B, bn0, N, k + GK2, k_end); }
+        if (more) { ra = tile_load128<LA>(A, bm0, M, k + GK2, k_end); rb = tile_load128<LB>(B, bn0, N, k + GK2, k_end); }
         const float *la = lds[buf][0] + wm + i, *lb = lds[buf][1] + wn + i;
 #pragma unroll
         for (int u = 0; u < GK2 / 2; u++) {
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, floa
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) { tile_store128(A, ra, lds[buf ^ 1][0]); tile_store128(B, rb, lds[buf ^ 1][1]); }
+        if (more) { tile_store128<LA>(ra, lds[buf ^ 1][0]); tile_store128<LB>(rb, lds[buf ^ 1][1]); }
         __syncthreads();
         buf ^= 1;
     }
@@ -372,6 +381,38 @@ __global__ __launch_bounds__(256) void gemm128_kernel(Operand A, Operand B, floa
     GemmEpilogue ee = epilogue_for_key(e, bt, key);
     if (n_slabs > 1) ee = GemmEpilogue{};                       // the epilogue then runs in gemm_reduce
     bool bad = false;
+    if (symmetric) {
+        const bool mirror = blockIdx.x > blockIdx.y;
+        const bool vec = (N & 3) == 0;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int64_t row0 = bm0 + wm + 32 * tm + 8 * g4 + 4 * kk, col = bn0 + wn + 32 * tn + i;
+                    f32x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float v = acc[tm][tn][4 * g4 + j];
+                        const int64_t row = row0 + j;
+                        if (row < M && col < N) {
+                            if (ee.axpy != nullptr) v = __builtin_fmaf(ee.axpy_a, ee.axpy[row * N + col], ee.axpy_b * v);
+                            c[row * N + col] = v;
+                        }
+                        v4[j] = v;
+                    }
+                    if (mirror && col < N) {
+                        if (vec && row0 + 4 <= M) *reinterpret_cast<f32x4 *>(c + col * N + row0) = v4;
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (row0 + j < M) c[col * N + row0 + j] = v4[j];
+                        }
+                    }
+                }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
@@ -454,7 +495,7 @@ struct GemmCtx {
 };
 const Batch ONE_KEY{1, 0, nullptr, nullptr};
 
-void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, const GemmEpilogue &e, const GemmCtx &g) {
+void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, const GemmEpilogue &e, const GemmCtx &g, bool symmetric = false) {
     const int count = g.bt.count;
     const bool big = M >= 256 && N >= 256;
     const int64_t T = big ? 128 : 64;                           // block tile
@@ -474,7 +515,20 @@ void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, const
     dim3 grid((unsigned)((N + T - 1) / T), (unsigned)((M + T - 1) / T), (unsigned)(z * count)), block(256);
     float *dst = z == 1 ? C : g.slabs;
     const GemmEpilogue none{};
-    if (big) MECHA_LAUNCH(MK_ROT_GEMM, gemm128_kernel, grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none);
+    // (symmetric products: the upper triangle only, when the epilogue runs in the kernel itself)
+    const int sym = (symmetric && z == 1 && M == N && C != nullptr && e.out == nullptr && e.minus == nullptr && e.plus == nullptr && e.mix == nullptr &&
+                     e.col_bias == nullptr) ? 1 : 0;
+    if (big) {
+        // the operand layouts are compiled in (a run-time choice cost 208 VGPRs and two waves per SIMD)
+        const int la = A.ms == 1 ? LAYOUT_M : (A.ks == 1 ? LAYOUT_K : LAYOUT_ANY), lb = B.ms == 1 ? LAYOUT_M : (B.ks == 1 ? LAYOUT_K : LAYOUT_ANY);
+#define MECHA_GEMM128(LA_, LB_) MECHA_LAUNCH(MK_ROT_GEMM, (gemm128_kernel<LA_, LB_>), grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none, sym)
+        if (la == LAYOUT_M && lb == LAYOUT_M) MECHA_GEMM128(LAYOUT_M, LAYOUT_M);
+        else if (la == LAYOUT_K && lb == LAYOUT_K) MECHA_GEMM128(LAYOUT_K, LAYOUT_K);
+        else if (la == LAYOUT_K && lb == LAYOUT_M) MECHA_GEMM128(LAYOUT_K, LAYOUT_M);
+        else if (la == LAYOUT_M && lb == LAYOUT_K) MECHA_GEMM128(LAYOUT_M, LAYOUT_K);
+        else MECHA_GEMM128(LAYOUT_ANY, LAYOUT_ANY);
+#undef MECHA_GEMM128
+    }
     else MECHA_LAUNCH(MK_ROT_GEMM, gemm_kernel, grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none);
     if (z > 1) {
         const int64_t total = M * N;
@@ -634,7 +688,7 @@ float *polar_step(float *cur, float *nxt, float *G, float *G2, int64_t r, int64_
     const int count = g.bt.count;
     const GemmEpilogue none{};
     // G[m][n] = sum_k cur[m][k] cur[n][k]
-    gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g);
+    gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g, true);
     if (first) {
         gram_norms(G, r, scal, g);
         const int64_t both = r * c + rr;
@@ -647,7 +701,7 @@ float *polar_step(float *cur, float *nxt, float *G, float *G2, int64_t r, int64_
     mix.axpy = G; mix.axpy_a = st.b; mix.axpy_b = st.c;
     // (G and b G + c G G are symmetric bit for bit -- the same products in the same order on both sides of the diagonal --
     //  so both operands are read along their rows: contiguous 16-byte loads)
-    gemm(Operand{G, r, 1}, Operand{G, r, 1}, G2, r, r, r, mix, g);
+    gemm(Operand{G, r, 1}, Operand{G, r, 1}, G2, r, r, r, mix, g, true);
     GemmEpilogue upd{};
     upd.axpy = cur; upd.axpy_a = st.a; upd.axpy_b = 1.0f;
     gemm(Operand{G2, r, 1}, Operand{cur, c, 1}, nxt, r, c, r, upd, g);
@@ -688,7 +742,7 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
         steps += easy.n;
         // has every singular value arrived?  G of the current X, its distance from the identity, one word per key
         const GemmEpilogue none{};
-        gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g);
+        gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g, true);
         gram_norms(G, r, scal, g);
         // |G - I|_F^2 = sum (sigma^2 - 1)^2: 1e-9 r allows an rms deviation of 1.6e-5 per singular value; 1e-13 r^2 is the
         // rounding floor of the fp32 Gram matrix itself

@@ -387,17 +387,21 @@ class HipBackend:
         # one index tensor for the whole wave: [flat keys..., group 0 keys..., group 1 keys...]; per-call flag words are
         # gathered back into the wave's order at the end
         order = flat + [i for idx in groups.values() for i in idx]
-        offs_all = torch.tensor([layout.offsets[i] for i in order], dtype=torch.int64).to(self.device)
+
+        def upload(values):                                     # pinned + non-blocking: the host must not wait for the stream here
+            return torch.tensor(values, dtype=torch.int64, pin_memory=True).to(self.device, non_blocking=True)
+        offs_all = upload([layout.offsets[i] for i in order] or [0])
         fl_all = torch.zeros(max(len(order), 1), dtype=torch.int32, device=self.device)
         pos = 0
         if flat:
-            segs = torch.tensor([[layout.offsets[i], layout.numels[i]] for i in flat], dtype=torch.int64).to(self.device)
+            segs = upload([[layout.offsets[i], layout.numels[i]] for i in flat])
             _lib.check(L.mecha_batched_weighted_sum(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(), segs.data_ptr(), len(flat),
                                                     layout.total_elems, in_dt, out_dt, alpha, fl_all.data_ptr(), stream), "batched lerp (rotate, ndim <= 1)")
             pos = len(flat)
         for (n, p), idx in groups.items():
             per_key = int(L.mecha_batched_rotate_workspace_bytes(n, p, 1))
             chunk = max(1, min(len(idx), self.ROTATE_WORKSPACE_BYTES // max(per_key, 1)))
+            chunk = -(-len(idx) // -(-len(idx) // chunk))          # equal shares when the group needs several calls
             for c0 in range(0, len(idx), chunk):
                 cnt = min(chunk, len(idx) - c0)
                 nbytes = int(L.mecha_batched_rotate_workspace_bytes(n, p, cnt))
@@ -407,7 +411,7 @@ class HipBackend:
                                                   ws.data_ptr(), ws.numel(), fl_all[pos + c0:].data_ptr(), stream), "mecha_batched_rotate")
             pos += len(idx)
         if order:
-            flags.index_copy_(0, torch.tensor(order, dtype=torch.int64).to(self.device), fl_all[:len(order)])
+            flags.index_copy_(0, upload(order), fl_all[:len(order)])
 
     def _rotate_ws(self, nbytes: int) -> torch.Tensor:
         """One growing workspace per backend: the calls of a wave run one after the other on the compute stream."""

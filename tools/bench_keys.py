@@ -38,7 +38,92 @@ def rotate_flops(n, p, iterations):
     return fixed + iterations * 4 * q * q * p
 
 
+def polar_step_flops(r, c):
+    """One step X <- a X + (b G + c G^2) X on an r x c matrix as rotate.hip runs it: G = X X^T and G G computed on and above
+    the diagonal only (128 x 128 tiles, outputs of 256 x 256 and more), the update in full."""
+    nt = -(-r // 128)
+    f = (nt + 1) / (2 * nt) if r >= 256 else 1.0
+    return 2 * r * r * c * f + 2 * r * r * r * f + 2 * r * r * c
+
+
+def rotate_flops_run(n, p, wide_keys_through_long_schedule=0.0):
+    """GEMM flops of one key on the batched path.  Tall: A^T B, 14 polar steps on p x p, the application.  Wide: two polar
+    solves of 6 steps + the Gram matrix of the convergence test (+ 14 steps for the given fraction of keys), five
+    n x n x p products."""
+    if n >= p:
+        return 4 * n * p * p + 14 * polar_step_flops(p, p)
+    nt = -(-n // 128)
+    f = (nt + 1) / (2 * nt) if n >= 256 else 1.0
+    per_solve = 6 * polar_step_flops(n, p) + 2 * n * n * p * f + wide_keys_through_long_schedule * 14 * polar_step_flops(n, p)
+    return 10 * n * n * p + 2 * per_solve
+
+
+def run_rotate_batched(args, device):
+    """The scheduler's form: both checkpoints' >= 2-D keys in two arenas, one mecha_batched_rotate launch sequence per 2-D
+    shape (merging.HipBackend._run_rotate).  Times every shape group on its own (a sync per group) and the whole job."""
+    import ctypes
+    from sd_mecha_amd.arena import plan_arena
+    from sd_mecha_amd.merging import HipBackend
+    keys = eligible(load_manifest("sdxl-sgm"))[::args.key_stride]
+    layout = plan_arena([(k, numel(s)) for k, s in keys])
+    gen = torch.Generator(device=device).manual_seed(7)
+    a = torch.empty(layout.total_elems, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
+    b = torch.empty(layout.total_elems, dtype=torch.bfloat16, device=device).normal_(0.0, 0.02, generator=gen)
+    out = torch.empty(layout.total_elems, dtype=torch.bfloat16, device=device)
+    backend = HipBackend(device)
+    L = backend.lib
+    groups = {}
+    for i, (k, shape) in enumerate(keys):
+        groups.setdefault(mm.rotate_shape_2d(shape), []).append(i)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    per_group = []
+    t_total, flops_total = 0.0, 0
+    for rep in range(args.warmup + 1):
+        per_group, t_total, flops_total = [], 0.0, 0
+        for (n, p), idx in sorted(groups.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1]):
+            offs = torch.tensor([layout.offsets[i] for i in idx], dtype=torch.int64).to(device)
+            flags = torch.zeros(len(idx), dtype=torch.int32, device=device)
+            per_key = int(L.mecha_batched_rotate_workspace_bytes(n, p, 1))
+            chunk = max(1, min(len(idx), HipBackend.ROTATE_WORKSPACE_BYTES // per_key))
+            chunk = -(-len(idx) // -(-len(idx) // chunk))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            short_ok = 0
+            for c0 in range(0, len(idx), chunk):
+                cnt = min(chunk, len(idx) - c0)
+                ws = backend._rotate_ws(int(L.mecha_batched_rotate_workspace_bytes(n, p, cnt)))
+                _lib.check(L.mecha_batched_rotate(a.data_ptr(), b.data_ptr(), out.data_ptr(), offs[c0:].data_ptr(), cnt, n, p, _lib.BF16, _lib.BF16,
+                                                  1.0, 1, 0.0, ws.data_ptr(), ws.numel(), flags[c0:].data_ptr(), stream), "mecha_batched_rotate")
+                if n < p:                                       # the per-key done words of the last polar solve head the workspace
+                    short_ok += int(ws[:4 * cnt].view(torch.int32).sum().item())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert int((flags & 1).sum().item()) == 0
+            # flops actually run: tall keys one 14-step solve; wide keys two solves of 6 steps + the Gram matrix of the test,
+            # + 14 more for the keys that failed it (counted from the second solve's words)
+            fl = len(idx) * rotate_flops_run(n, p, (len(idx) - short_ok) / len(idx) if n < p else 0.0)
+            per_group.append({"shape": [n, p], "keys": len(idx), "ms": round(dt * 1e3, 2), "tflops": round(fl / dt / 1e12, 1),
+                              **({"left_after_short_schedule": short_ok} if n < p else {})})
+            t_total += dt
+            flops_total += fl
+    done_bytes = layout.payload_elems * 2 * 3
+    return {
+        "metric": "merged state-dict GB/s", "value": round(done_bytes / t_total / 1e9, 3), "unit": "GB/s", "n_gpus": 1,
+        "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "sdxl_rotate", "description": "SDXL svd.rotate(a, b, alignment=1.0, alpha=0.0), every >=2-D key of 2 random-init bf16 checkpoints, "
+                   "bf16 out, batched by 2-D shape (one launch sequence per shape)", "keys": len(keys), "key_stride": args.key_stride, "shape_groups": len(groups)},
+        "seconds": round(t_total, 3), "keys_per_second": round(len(keys) / t_total, 2),
+        "roofline": {"bound": "mfma", "kernel": "rotate_gemm_f32mfma", "achieved": round(flops_total / t_total / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(flops_total / t_total / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "algorithmic_flops": flops_total, "note": "GEMM flops actually run (short polar schedule where a key's convergence word allowed it) over the "
+                     "wall time of all launch sequences, norms / centring / reductions included"},
+        "groups": per_group[:16],
+    }
+
+
 def run_rotate(args, device):
+    if args.batched:
+        return run_rotate_batched(args, device)
     keys = eligible(load_manifest("sdxl-sgm"))
     keys.sort(key=lambda kv: -numel(kv[1]))
     keys = keys[::args.key_stride]
@@ -194,6 +279,7 @@ def main():
     ap.add_argument("--rank", type=int, default=32, help="sdxl_lora: rank of every network (BASELINE config 5: 32)")
     ap.add_argument("--ignore-flags", action="store_true", help="timing experiments with deliberately broken kernels only")
     ap.add_argument("--threads", type=int, default=1, help="sdxl_rotate: worker threads, each with its own HIP stream")
+    ap.add_argument("--batched", action="store_true", help="sdxl_rotate: one mecha_batched_rotate launch sequence per 2-D shape (the scheduler's form)")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "needs a GPU"
     device = torch.device("cuda", 0)
