@@ -680,10 +680,13 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     is_cuda = dev.type == "cuda"
     n_models = len(plan.models)
     in_esz, out_esz = DTYPE_REVERSE_MAPPING[in_dtype][1], DTYPE_REVERSE_MAPPING[output_dtype][1]
-    # buffer sets (2 = double buffering), each holding n_models inputs + 1 output; the budget is shared between them
+    # pinned staging: n_sets input sets (2 = double buffering: wave w + 1 is read from the files while wave w crosses the link)
+    # and a ring of n_outs output buffers of their own (the file writer may lag two waves behind the link without holding up
+    # the next wave's upload: with the output buffer inside the set, H2D of wave w + 2 waited for the write of wave w); the
+    # budget covers all of them
     n_sets = max(1, int(os.environ.get("MECHA_BUFFER_SETS", "2")))
-    per_set = max(total_buffer_size // n_sets, 1 << 16)
-    wave_elems = max(per_set // (n_models * in_esz + out_esz), 1024)
+    n_outs = max(n_sets, int(os.environ.get("MECHA_OUT_BUFFERS", str(n_sets + 2))))
+    wave_elems = max(max(total_buffer_size, 1 << 16) // (n_sets * n_models * in_esz + n_outs * out_esz), 1024)
     waves, split_waves = _plan_waves(items, wave_elems)
     if not waves and not split_waves:
         return
@@ -696,7 +699,7 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
         pin = dict(pin_memory=True) if is_cuda else {}
         return {
             "h_in": [torch.empty(cap, dtype=in_dtype, **pin) for _ in range(n_models)],
-            "h_out": torch.empty(cap, dtype=output_dtype, **pin),
+            "h_out": None, "out_slot": None,
             "h_flags_pinned": torch.empty(max((len(w.layout.keys) for w in waves), default=1), dtype=torch.int32, **pin),
             "d_in": [torch.empty(cap_dev, dtype=in_dtype, device=dev) for _ in range(n_models)],
             "d_out": torch.empty(cap_dev, dtype=output_dtype, device=dev),
@@ -704,7 +707,10 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
         }
     with _phase("alloc"):
         sets = [alloc_set() for _ in range(min(n_sets, max(len(waves), 2 if split_waves else 1)))]
-    last_stats["pinned_bytes"] = max(last_stats.get("pinned_bytes", 0), len(sets) * cap * (n_models * in_esz + out_esz))
+        pin_out = dict(pin_memory=True) if is_cuda else {}
+        outs = [{"h_out": torch.empty(cap, dtype=output_dtype, **pin_out)} for _ in range(min(n_outs, max(len(waves), 2 if split_waves else 1)))]
+    out_cursor = [0]
+    last_stats["pinned_bytes"] = max(last_stats.get("pinned_bytes", 0), cap * (len(sets) * n_models * in_esz + len(outs) * out_esz))
     last_stats["split_keys"] = last_stats.get("split_keys", 0) + len(split_waves)
     s_copy_in = backend.stream() if is_cuda else None
     s_comp = backend.stream() if is_cuda else None
@@ -740,14 +746,20 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
         _lib.check(hostlib.mecha_host_pread_many(fds_a.ctypes.data, dst_a.ctypes.data, size_a.ctypes.data, foff_a.ctypes.data,
                                                  len(fds_a), host_threads), "mecha_host_pread_many")
 
-    def wait_write(bs):
-        fut = bs.pop("write_fut", None)
+    def wait_write(slot):
+        fut = slot.pop("write_fut", None)
         if fut is not None:
             with _phase("wait_write"):
                 fut.result()
 
+    def next_out():
+        """The next output buffer of the ring, once the file writer is done with what it held."""
+        slot = outs[out_cursor[0] % len(outs)]
+        out_cursor[0] += 1
+        wait_write(slot)
+        return slot
+
     def launch(bs, wave: _Wave):
-        wait_write(bs)
         L = wave.layout
         bs["wave"] = wave
         segs_host = L.host_segments()
@@ -780,6 +792,8 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             if is_cuda:
                 bs["ev_comp"] = torch.cuda.Event()
                 bs["ev_comp"].record(s_comp)
+        bs["out_slot"] = next_out()                         # only the copy back needs it: uploads and kernels are already enqueued
+        bs["h_out"] = bs["out_slot"]["h_out"]
         ctx_out = torch.cuda.stream(s_copy_out) if is_cuda else _null()
         with ctx_out:
             if is_cuda:
@@ -832,7 +846,7 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             def write(keys=put_keys, metas=put_metas, ptrs=put_ptrs):
                 with _phase("write"):
                     sink.put_many(keys, metas, ptrs, host_threads)
-            bs["write_fut"] = writer.submit(write)
+            bs["out_slot"]["write_fut"] = writer.submit(write)
         bs["wave"] = None
 
     def run_split(wave: _Wave):
@@ -899,21 +913,20 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
         region = sink.reserve(key, meta) if to_file else None
         whole = None if (to_file or discard) else torch.empty(n, dtype=output_dtype)
         for i, (s0, cnt) in enumerate(pieces):
-            bs = sets[i % len(sets)]
-            wait_write(bs)                                             # this set's h_out may still be on its way to the file
+            slot = next_out()                                          # its last piece may still be on its way to the file
             with (torch.cuda.stream(s_copy_out) if is_cuda else _null()):
-                bs["h_out"][:cnt].copy_(big_out[s0:s0 + cnt], non_blocking=True)
+                slot["h_out"][:cnt].copy_(big_out[s0:s0 + cnt], non_blocking=True)
                 if is_cuda:
                     ev = torch.cuda.Event()
                     ev.record(s_copy_out)
                     ev.synchronize()
             if to_file:
-                def write(ptr=bs["h_out"].data_ptr(), off=region + s0 * out_esz, nb=cnt * out_esz):
+                def write(ptr=slot["h_out"].data_ptr(), off=region + s0 * out_esz, nb=cnt * out_esz):
                     with _phase("write"):
                         sink.write_at(off, ptr, nb, host_threads)
-                bs["write_fut"] = writer.submit(write)
+                slot["write_fut"] = writer.submit(write)
             elif not discard:
-                whole[s0:s0 + cnt].copy_(bs["h_out"][:cnt])
+                whole[s0:s0 + cnt].copy_(slot["h_out"][:cnt])
         if whole is not None:
             t = whole.view(meta.shape)
             sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t
@@ -935,13 +948,13 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     with _phase("drain"):
         for bs in sets:
             drain(bs)
-    for bs in sets:
-        wait_write(bs)
+    for slot in outs:
+        wait_write(slot)
     for wave in split_waves:
         with _phase("split_transfer"):
             run_split(wave)
-    for bs in sets:
-        wait_write(bs)
+    for slot in outs:
+        wait_write(slot)
     writer.shutdown()
     if is_cuda:
         torch.cuda.synchronize(dev)
