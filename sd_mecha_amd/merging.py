@@ -190,9 +190,10 @@ class _LoraStore:
     def __init__(self, plan: FusedPlan, readers, device: torch.device, host_threads: int):
         self.expr = plan.params["expr"]
         self.files = []
+        self.tables_by_file: List[dict] = []
         for node in plan.params["loras"]:
             reader = readers[id(node)]
-            names = [k for k, m in reader.metadata() if k.endswith(lora_mod.UP) or k.endswith(lora_mod.DOWN)]
+            names = [k for k, m in reader.metadata() if k.endswith(lora_mod.UP) or k.endswith(lora_mod.DOWN) or k.endswith("." + lora_mod.ALPHA)]
             offs, total = {}, 0
             for k in names:
                 offs[k] = total
@@ -208,11 +209,84 @@ class _LoraStore:
                                                             len(names), host_threads), "mecha_host_pread_many")
             dev_buf = host.to(device) if device.type == "cuda" else host
             self.files.append((reader, dev_buf, offs))
+            # per base-key prefix: (device address of up, of down, rank, scale) -- what a network descriptor holds, computed once
+            # per file instead of once per (key, network, wave): alpha / rank as fp32 arithmetic (lycoris.py:263)
+            base_ptr = dev_buf.data_ptr()
+            host_np = host.numpy()
+            table = {}
+            for k in names:
+                if not k.endswith(lora_mod.UP):
+                    continue
+                prefix = k[:-len(lora_mod.UP) - 1]
+                down_k, alpha_k, mid_k = f"{prefix}.{lora_mod.DOWN}", f"{prefix}.{lora_mod.ALPHA}", f"{prefix}.{lora_mod.MID}"
+                if down_k not in offs or mid_k in reader:
+                    continue                                     # incomplete pair / Tucker network: the slow path reports it
+                um, dm = reader.meta(k), reader.meta(down_k)
+                rank = int(dm.shape[0])
+                scale = 1.0
+                if alpha_k in offs:                              # the scalar sits in the staging buffer already: no tensor per network
+                    am = reader.meta(alpha_k)
+                    raw = host_np[offs[alpha_k]:offs[alpha_k] + am.nbytes()]
+                    if am.dtype == torch.bfloat16:
+                        alpha = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)[0]
+                    else:
+                        alpha = np.float32(raw.view({torch.float16: np.float16, torch.float32: np.float32, torch.float64: np.float64}[am.dtype])[0])
+                    scale = float(np.float32(alpha) / np.float32(rank))
+                table[prefix] = (base_ptr + offs[k], base_ptr + offs[down_k], rank, scale, tuple(um.shape), tuple(dm.shape), um.dtype, dm.dtype)
+            self.tables_by_file.append(table)
 
     def _tensor(self, f: int, name: str) -> torch.Tensor:
         reader, buf, offs = self.files[f]
         m = reader.meta(name)
         return buf[offs[name]:offs[name] + m.nbytes()].view(m.dtype).view(tuple(m.shape))
+
+    KEY_DTYPE = np.dtype([("offset", "<i8"), ("rows", "<i8"), ("cols", "<i8"), ("tile_start", "<i8"), ("net_begin", "<i4"), ("net_count", "<i4")])
+    NET_DTYPE = np.dtype([("up", "<u8"), ("down", "<u8"), ("rank", "<i4"), ("scale", "<f4"), ("weight", "<f4"), ("reserved", "<i4")])
+
+    def tables(self, layout: ArenaLayout, header):
+        """The wave's descriptor tables as numpy records laid out like mecha_lora_key / mecha_lora_net (include/mecha_hip.h):
+        (indices of the merged keys inside the wave, key records, network records, {skipped keys}, factor dtype).  Same
+        per-key rule as entries(); no tensor objects, no ctypes structs -- the tables of an SDXL wave (1 071 keys x 16
+        networks) took 0.5 s to build that way."""
+        idx, keys, nets, skip = [], [], [], set()
+        tile = 0
+        lora_dtype = None
+        T = _lib.LORA_TILE
+        n_files = len(self.files)
+        for index, (key, off, n) in enumerate(zip(layout.keys, layout.offsets, layout.numels)):
+            shape = tuple(header[key].shape)
+            prefix = lora_mod.lora_key_prefix(key, shape)
+            found = [self.tables_by_file[i].get(prefix) if prefix is not None else None for i in range(n_files)]
+            if prefix is not None:
+                for i in range(n_files):                            # anything the fast table left out goes the careful way
+                    if found[i] is None and f"{prefix}.{lora_mod.UP}" in self.files[i][0]:
+                        lora_mod.network_entries(self.files[i][0], prefix)       # raises for Tucker networks
+            try:
+                applied = lora_mod.networks_for_key(self.expr, lambda i: found[i] is not None)
+            except StateDictKeyError:
+                skip.add(key)
+                continue
+            if not n:
+                continue
+            rows = shape[0] if len(shape) >= 2 else 1
+            cols = n // rows if rows else 0
+            begin = len(nets)
+            for i, w in applied:
+                if math.isclose(float(w), 0.0):
+                    continue
+                up_ptr, down_ptr, rank, scale, ushape, dshape, udt, ddt = found[i]
+                if ushape[0] != rows or math.prod(ushape[1:]) != rank or math.prod(dshape[1:]) != cols:
+                    raise ValueError(f"{key}: LoRA {i} holds up {ushape} / down {dshape}, the key is {rows} x {cols}")
+                if udt not in (torch.float16, torch.bfloat16) or ddt != udt or (lora_dtype or udt) != udt:
+                    raise NotImplementedError("LoRA factors of one batch must share one of float16 / bfloat16")
+                lora_dtype = udt
+                nets.append((up_ptr, down_ptr, rank, scale, float(w), 0))
+            if len(nets) - begin > _lib.MAX_MODELS:
+                raise ValueError(f"at most {_lib.MAX_MODELS} networks per key")
+            idx.append(index)
+            keys.append((off, rows, cols, tile, begin, len(nets) - begin))
+            tile += ((cols + T - 1) // T) * ((rows + T - 1) // T)
+        return (np.asarray(idx, dtype=np.int64), np.array(keys, dtype=self.KEY_DTYPE), np.array(nets, dtype=self.NET_DTYPE), skip, lora_dtype)
 
     def entries(self, layout: ArenaLayout, header) -> Tuple[list, set]:
         """([(index in the wave, offset, rows, cols, [(up, down, alpha, weight), ...])] for the keys of a wave that are merged,
@@ -429,6 +503,23 @@ class HipBackend:
         entry_flags = torch.zeros(len(entries), dtype=torch.int32, device=self.device)
         batch.run(base, out, entry_flags)
         flags.index_copy_(0, torch.tensor([i for i, *_ in entries], dtype=torch.int64, device=self.device), entry_flags)
+
+    def run_lora_tables(self, tables, base: torch.Tensor, out: torch.Tensor, flags: torch.Tensor) -> None:
+        """run_lora from the numpy descriptor tables of _LoraStore.tables: two uploads and one launch per wave."""
+        import ctypes
+        idx, keys, nets, _, lora_dtype = tables
+        if not len(idx):
+            return
+        if not len(nets):
+            nets = np.zeros(1, dtype=nets.dtype)
+        keys_dev = torch.from_numpy(keys.view(np.uint8).reshape(-1)).to(self.device)
+        nets_dev = torch.from_numpy(nets.view(np.uint8).reshape(-1)).to(self.device)
+        entry_flags = torch.zeros(len(idx), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.mecha_batched_lora_accumulate(
+            base.data_ptr(), out.data_ptr(), keys_dev.data_ptr(), keys.ctypes.data, len(idx), nets_dev.data_ptr(), nets.ctypes.data,
+            _DT_CODE[base.dtype], _DT_CODE[out.dtype], _DT_CODE[lora_dtype or torch.float16], entry_flags.data_ptr(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mecha_batched_lora_accumulate")
+        flags.index_copy_(0, torch.from_numpy(idx).to(self.device), entry_flags)
 
     def workspace_bytes(self, plan: FusedPlan, layout: ArenaLayout) -> int:
         if plan.kind == "ties":
@@ -718,7 +809,10 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
 
     host_threads = max(1, min(int(os.environ.get("MECHA_HOST_THREADS", "16")), os.cpu_count() or 1))
     writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
-    lora_store = _LoraStore(plan, readers, dev, host_threads) if plan.kind == "lora" else None
+    lora_store = None
+    if plan.kind == "lora":
+        with _phase("lora_load"):
+            lora_store = _LoraStore(plan, readers, dev, host_threads)
     hostlib = _lib.lib()
 
     def stage(bs, wave: _Wave):
@@ -781,7 +875,11 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             flags = torch.zeros(len(L.keys), dtype=torch.int32, device=dev)
             nbytes = backend.workspace_bytes(plan, L)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if nbytes else None
-            if plan.kind == "lora":
+            if plan.kind == "lora" and hasattr(backend, "run_lora_tables"):
+                tables = lora_store.tables(L, header)
+                bs["skip"] = tables[3]
+                backend.run_lora_tables(tables, bs["d_in"][0][:L.total_elems], bs["d_out"][:L.total_elems], flags)
+            elif plan.kind == "lora":
                 entries, bs["skip"] = lora_store.entries(L, header)
                 backend.run_lora(entries, bs["d_in"][0][:L.total_elems], bs["d_out"][:L.total_elems], flags)
             else:
@@ -892,7 +990,11 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             nbytes = backend.workspace_bytes(plan, L)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if nbytes else None
             skip = ()
-            if plan.kind == "lora":
+            if plan.kind == "lora" and hasattr(backend, "run_lora_tables"):
+                tables = lora_store.tables(L, header)
+                skip = tables[3]
+                backend.run_lora_tables(tables, big_in[0], big_out, flags)
+            elif plan.kind == "lora":
                 entries, skip = lora_store.entries(L, header)
                 backend.run_lora(entries, big_in[0], big_out, flags)
             else:

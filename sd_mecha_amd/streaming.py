@@ -44,7 +44,7 @@ class TensorMetadata:
     __slots__ = ("shape", "dtype", "start", "end")
 
     def __init__(self, shape, dtype, start=0, end=0):
-        self.shape = tuple(int(s) for s in shape)
+        self.shape = tuple(map(int, shape))
         self.dtype = dtype
         self.start, self.end = int(start), int(end)
 
