@@ -94,6 +94,16 @@ int mecha_cast(const void *a, void *out, int64_t numel, int in_dtype, int out_dt
 int mecha_weighted_sum(const void *a, const void *b, void *out, int64_t numel,
                        int in_dtype, int out_dtype, float alpha, uint32_t *flags, void *stream);
 
+/* weighted_sum / add_difference with a FULL alpha tensor (linear.py:16, :23, :71, :76: `alpha.numel() > 1`, no 0 / 1
+ * shortcut -- block weights, per-row or per-element weights).  `alpha`: DEVICE fp32, one weight per element of `a` (the shim
+ * broadcasts the reference's tensor to the shape of `a`), 32-byte aligned for the vector path.  The same single fma per
+ * element as the scalar forms (torch's lerp_vec blends coefficient and base per element; addcmul = fma(b, alpha, a)).
+ * The weights are hyper-parameters: they take no part in the omit_non_finite flag.  Algorithmic bytes: + 4 per element. */
+int mecha_weighted_sum_tensor(const void *a, const void *b, const float *alpha, void *out, int64_t numel,
+                              int in_dtype, int out_dtype, uint32_t *flags, void *stream);
+int mecha_add_difference_tensor(const void *a, const void *b, const float *alpha, void *out, int64_t numel,
+                                int in_dtype, int out_dtype, uint32_t *flags, void *stream);
+
 /* n_average (linear.py:26-40): running mean res = lerp(res, m_i, 1/i), i = 2..N.
  * `models` is a HOST array of n_models device pointers (1 <= n_models <= MECHA_MAX_MODELS). */
 int mecha_n_average(const void *const *models, int n_models, void *out, int64_t numel,

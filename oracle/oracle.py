@@ -63,6 +63,8 @@ def lib() -> ctypes.CDLL:
         L.orc_apply_mask.argtypes = [c_p, c_p, c_p, c_i64]
         L.orc_div_scalar.argtypes = [c_p, c_f, c_p, c_i64]
         L.orc_lora_delta.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_f, c_i, c_p]
+        L.orc_lerp_tensor.argtypes = [c_p, c_p, c_p, c_p, c_i64]
+        L.orc_addcmul_tensor.argtypes = [c_p, c_p, c_p, c_p, c_i64]
         _lib = L
     return _lib
 
@@ -117,9 +119,20 @@ def lerp(a, b, w: float) -> np.ndarray:
     return out
 
 
-def weighted_sum(a, b, alpha: float = 0.5) -> np.ndarray:
-    """linear.py:7-23."""
-    alpha = float(np.float32(alpha))         # alpha arrives as a 0-d fp32 tensor (merging.py:632-633)
+def _alpha_tensor(alpha, like: np.ndarray) -> np.ndarray:
+    """A full alpha tensor broadcast to the shape of `a` (torch broadcasting rules), fp32."""
+    return np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float32), like.shape))
+
+
+def weighted_sum(a, b, alpha=0.5) -> np.ndarray:
+    """linear.py:7-23.  alpha: a scalar, or an array with more than one element (no 0 / 1 shortcut then, :16)."""
+    if np.ndim(alpha) > 0 and np.size(alpha) > 1:
+        a, b = _f32(a), _f32(b)
+        w = _alpha_tensor(alpha, a)
+        out = np.empty_like(a)
+        lib().orc_lerp_tensor(_p(a), _p(b), _p(w), _p(out), a.size)
+        return out
+    alpha = float(np.float32(np.asarray(alpha).reshape(-1)[0] if np.ndim(alpha) > 0 else alpha))         # alpha arrives as a 0-d fp32 tensor (merging.py:632-633)
     if isclose(alpha, 0.0):
         return _f32(a)
     if isclose(alpha, 1.0):
@@ -136,9 +149,15 @@ def n_average(models: Sequence[np.ndarray]) -> np.ndarray:
     return out
 
 
-def add_difference(a, b, alpha: float = 1.0) -> np.ndarray:
-    """linear.py:64-76 (method body; the ``| a`` fallback of wrappers.py:9-39 is graph-level)."""
-    alpha = float(np.float32(alpha))
+def add_difference(a, b, alpha=1.0) -> np.ndarray:
+    """linear.py:64-76 (method body; the ``| a`` fallback of wrappers.py:9-39 is graph-level).  alpha: scalar or full tensor."""
+    if np.ndim(alpha) > 0 and np.size(alpha) > 1:
+        a, b = _f32(a), _f32(b)
+        w = _alpha_tensor(alpha, a)
+        out = np.empty_like(a)
+        lib().orc_addcmul_tensor(_p(a), _p(b), _p(w), _p(out), a.size)
+        return out
+    alpha = float(np.float32(np.asarray(alpha).reshape(-1)[0] if np.ndim(alpha) > 0 else alpha))
     if isclose(alpha, 0.0):
         return _f32(a)
     a, b = _f32(a), _f32(b)

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mecha_weighted_sum": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p, c_p]),
     "mecha_n_average": (c_i, [c_p, c_i, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "mecha_add_difference": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p, c_p]),
+    "mecha_weighted_sum_tensor": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "mecha_add_difference_tensor": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "mecha_subtract": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "mecha_scale": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_f, c_p, c_p]),
     "mecha_reduce_workspace_bytes": (c_sz, [c_i64]),

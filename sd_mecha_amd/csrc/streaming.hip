@@ -15,7 +15,7 @@
 
 namespace {
 
-enum : int { OP_CAST = 0, OP_LERP, OP_NAVG, OP_ADDCMUL, OP_SUB, OP_SCALE };
+enum : int { OP_CAST = 0, OP_LERP, OP_NAVG, OP_ADDCMUL, OP_SUB, OP_SCALE, OP_LERP_T, OP_ADDCMUL_T };
 
 struct EwParams {
     const void *in[MECHA_MAX_MODELS];
@@ -23,6 +23,7 @@ struct EwParams {
     float alpha;          // LERP: w; ADDCMUL/SCALE: alpha
     float alpha_m1;       // LERP: w - 1 (fp32)
     int small;            // LERP: |w| < 0.5
+    const float *alpha_t; // LERP_T / ADDCMUL_T: one fp32 weight per element (a full alpha tensor, broadcast by the caller)
     float w[MECHA_MAX_MODELS];     // NAVG: fp32(1/i) for model index i-1
     float wm1[MECHA_MAX_MODELS];   // NAVG: w - 1
 };
@@ -88,6 +89,23 @@ __device__ __forceinline__ void compute8(const EwParams &p, int64_t i, int valid
         for (int j = 0; j < 8; j++) {
             bad_in |= nonfinite_f32(a[j]);
             r[j] = (OP == OP_CAST) ? a[j] : a[j] * p.alpha;
+        }
+    } else if constexpr (OP == OP_LERP_T || OP == OP_ADDCMUL_T) {
+        // a weight per element (linear.py:23 / :76 with alpha.numel() > 1): the same single fma as the scalar forms, torch's
+        // vector kernels blend coefficient and base per element (cpu/LerpKernel.cpp lerp_vec; addcmul = fma(b, alpha, a))
+        float a[8], b[8], w[8];
+        ld(p.in[0], a);
+        ld(p.in[1], b);
+        if constexpr (VEC) load8<MECHA_F32, true>(p.alpha_t, i, w);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) w[j] = (j < valid) ? p.alpha_t[i + j] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            bad_in |= nonfinite_f32(a[j]) | nonfinite_f32(b[j]);          // the weights are hyper-parameters: no omit_non_finite on them
+            if constexpr (OP == OP_LERP_T) r[j] = lerp_torch(a[j], b[j], w[j], w[j] - 1.0f, __builtin_fabsf(w[j]) < 0.5f);
+            else r[j] = __builtin_fmaf(b[j], w[j], a[j]);
         }
     } else {
         float a[8], b[8];
@@ -165,6 +183,10 @@ int launch_ew(EwParams &p, void *out, int64_t total, int in_dt, int out_dt, cons
     for (int m = 0; m < p.n_in; m++) {
         MECHA_REQUIRE(p.in[m] != nullptr, "input %d is NULL", m);
         vec = vec && mecha_aligned16(p.in[m]);
+    }
+    if constexpr (OP == OP_LERP_T || OP == OP_ADDCMUL_T) {
+        MECHA_REQUIRE(p.alpha_t != nullptr, "alpha tensor is NULL");
+        vec = vec && ((reinterpret_cast<uintptr_t>(p.alpha_t) & 31u) == 0);          // two 16-byte loads per 8 weights
     }
     const int64_t n_vec = (total + 7) >> 3;
     const int64_t blocks = (n_vec + MECHA_BLOCK - 1) / MECHA_BLOCK;
@@ -250,6 +272,22 @@ int mecha_n_average(const void *const *models, int n_models, void *out, int64_t 
 int mecha_add_difference(const void *a, const void *b, void *out, int64_t numel, int in_dtype, int out_dtype, float alpha,
                          uint32_t *flags, void *stream) {
     return add_difference_impl(a, b, out, numel, in_dtype, out_dtype, alpha, nullptr, 0, flags, stream);
+}
+
+int mecha_weighted_sum_tensor(const void *a, const void *b, const float *alpha, void *out, int64_t numel, int in_dtype, int out_dtype,
+                              uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(out != nullptr || numel == 0, "out is NULL");
+    EwParams p{};
+    p.n_in = 2; p.in[0] = a; p.in[1] = b; p.alpha_t = alpha;
+    return launch_ew<OP_LERP_T>(p, out, numel, in_dtype, out_dtype, nullptr, 0, flags, stream);
+}
+
+int mecha_add_difference_tensor(const void *a, const void *b, const float *alpha, void *out, int64_t numel, int in_dtype, int out_dtype,
+                                uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(out != nullptr || numel == 0, "out is NULL");
+    EwParams p{};
+    p.n_in = 2; p.in[0] = a; p.in[1] = b; p.alpha_t = alpha;
+    return launch_ew<OP_ADDCMUL_T>(p, out, numel, in_dtype, out_dtype, nullptr, 0, flags, stream);
 }
 
 int mecha_subtract(const void *a, const void *b, void *out, int64_t numel, int in_dtype, int out_dtype, uint32_t *flags,

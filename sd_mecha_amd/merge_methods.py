@@ -79,9 +79,23 @@ def _alpha(alpha) -> float:
     """Scalar hyper-parameters arrive as 0-d fp32 tensors in the reference (merging.py:632-633)."""
     if isinstance(alpha, torch.Tensor):
         if alpha.numel() != 1:
-            raise NotImplementedError("per-element alpha tensors are outside the MI355X hot path (SURVEY §8 a7)")
+            raise NotImplementedError("this method takes a scalar alpha on the MI355X path (weighted_sum and add_difference take full tensors)")
         alpha = alpha.item()
     return float(torch.tensor(float(alpha), dtype=torch.float32).item())
+
+
+def _is_full_alpha(alpha) -> bool:
+    """linear.py:16, :71: the 0 / 1 shortcuts apply to `alpha.numel() == 1` only; anything larger is a weight per element."""
+    return isinstance(alpha, torch.Tensor) and alpha.numel() > 1
+
+
+def _alpha_like(alpha: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """A full alpha tensor as the kernels take it: fp32, on the device, broadcast to the shape of `a` (torch.lerp / addcmul
+    broadcast it the same way; a result larger than `a` is refused -- the reference would return a bigger tensor)."""
+    w = alpha.to(device=like.device, dtype=torch.float32)
+    if torch.broadcast_shapes(tuple(w.shape), tuple(like.shape)) != tuple(like.shape):
+        raise ValueError(f"alpha of shape {tuple(alpha.shape)} does not broadcast to the key's shape {tuple(like.shape)}")
+    return w.expand(like.shape).contiguous()
 
 
 class _Flags:
@@ -132,7 +146,18 @@ def omit_non_finite(a, *, key=None) -> torch.Tensor:
 
 # ------------------------------------------------------------------ linear.py
 def weighted_sum(a, b, alpha=0.5, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
-    """weighted_sum (linear.py:7-23).  alpha == 0 returns a, alpha == 1 returns b, without touching the other."""
+    """weighted_sum (linear.py:7-23).  alpha == 0 returns a, alpha == 1 returns b, without touching the other; a full alpha
+    tensor (block weights: one weight per row / element) is lerp with a weight per element."""
+    if _is_full_alpha(alpha):
+        a, b = _c(_resolve(a, key)), _c(_resolve(b, key))
+        _check_inputs([a, b], "weighted_sum")
+        w = _alpha_like(alpha, a)
+        out = _out(a, out_dtype)
+        fl = _Flags(a.device, flags, check_finite)
+        _lib.check(_lib.lib().mecha_weighted_sum_tensor(a.data_ptr(), b.data_ptr(), w.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype],
+                                                        _DT[out.dtype], fl.ptr, _stream()), "mecha_weighted_sum_tensor")
+        fl.finish(key)
+        return out
     al = _alpha(alpha)
     if math.isclose(al, 0.0):
         return cast(a, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)
@@ -164,7 +189,18 @@ def n_average(*models, key=None, out_dtype=None, flags=None, check_finite=True) 
 
 
 def add_difference(a, b, alpha=1.0, *, key=None, out_dtype=None, flags=None, check_finite=True) -> torch.Tensor:
-    """add_difference (linear.py:64-76): a.addcmul(b, alpha); alpha == 0 returns a."""
+    """add_difference (linear.py:64-76): a.addcmul(b, alpha); alpha == 0 returns a; a full alpha tensor weighs every element."""
+    if _is_full_alpha(alpha):
+        b = _c(_resolve(b, key))
+        a = _c(_resolve(a, key))
+        _check_inputs([a, b], "add_difference")
+        w = _alpha_like(alpha, a)
+        out = _out(a, out_dtype)
+        fl = _Flags(a.device, flags, check_finite)
+        _lib.check(_lib.lib().mecha_add_difference_tensor(a.data_ptr(), b.data_ptr(), w.data_ptr(), out.data_ptr(), a.numel(), _DT[a.dtype],
+                                                          _DT[out.dtype], fl.ptr, _stream()), "mecha_add_difference_tensor")
+        fl.finish(key)
+        return out
     al = _alpha(alpha)
     if math.isclose(al, 0.0):
         return cast(a, out_dtype or torch.float32, key=key, flags=flags, check_finite=check_finite)

@@ -99,6 +99,26 @@ def gen_streaming(out):
     out["n_cases"] = np.array(case)
 
 
+def gen_alpha_tensor(out):
+    """weighted_sum / add_difference with a FULL alpha tensor (linear.py:16-23, :71-76: alpha.numel() > 1): one weight per
+    element, per row (broadcast) and per column, weights on both sides of torch.lerp's |w| < 0.5 test."""
+    rng = np.random.default_rng(20261110)
+    case = 0
+    for shape, ashape in [((33, 7), (33, 7)), ((64, 96), (64, 1)), ((64, 96), (96,)), ((8, 4, 3, 3), (8, 1, 1, 1)), ((8, 4, 3, 3), (8, 4, 3, 3)), ((7,), (7,))]:
+        for dtype in ("bfloat16", "float16"):
+            a, b = rand_half(rng, shape, dtype), rand_half(rng, shape, dtype)
+            alpha = torch.from_numpy(rng.uniform(-0.25, 1.25, size=ashape).astype(np.float32))
+            pre = f"a{case}"
+            out[pre + "_a"], out[pre + "_b"], out[pre + "_alpha"] = bits(a), bits(b), bits(alpha)
+            out[pre + "_dtype"] = np.array(dtype)
+            out[pre + "_shape"] = np.array(shape, dtype=np.int64)
+            out[pre + "_alpha_shape"] = np.array(ashape, dtype=np.int64)
+            out[pre + "_wsum"] = bits(linear.weighted_sum.__wrapped__(sd(a.float()), sd(b.float()), alpha, key="k"))
+            out[pre + "_adddiff"] = bits(linear.add_difference.__wrapped__(sd(a.float()), sd(b.float()), alpha, key="k"))
+            case += 1
+    out["n_cases"] = np.array(case)
+
+
 def gen_ties(out):
     rng = np.random.default_rng(1708)
     case = 0
@@ -566,7 +586,7 @@ def gen_configs(out):
 def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
     only = set(sys.argv[1:])
-    for name, fn in [("streaming", gen_streaming), ("ties", gen_ties), ("dare", gen_dare), ("stock_dropout", gen_stock_dropout),
+    for name, fn in [("streaming", gen_streaming), ("alpha_tensor", gen_alpha_tensor), ("ties", gen_ties), ("dare", gen_dare), ("stock_dropout", gen_stock_dropout),
                      ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_mixed", gen_e2e_mixed), ("e2e_alias", gen_e2e_alias), ("e2e_lora", gen_e2e_lora), ("mecha_text", gen_mecha_text),
                      ("configs", gen_configs)]:
         if only and name not in only:

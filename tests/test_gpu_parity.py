@@ -74,6 +74,35 @@ def test_golden_streaming_bit_exact(amd):
         assert np.array_equal(host_bits(amd.weighted_sum(a, b, 0.3, out_dtype=torch.float16)).reshape(-1), g[f"{pre}_wsum_0.3_as_f16"].reshape(-1))
 
 
+def test_golden_alpha_tensor_bit_exact(amd, oracle):
+    """A full alpha tensor (block weights: per element, per row, per column) through mecha_weighted_sum_tensor /
+    mecha_add_difference_tensor: the reference's bodies bit for bit, then a larger ragged case against the oracle."""
+    g = load_golden("alpha_tensor")
+    for c in range(int(g["n_cases"])):
+        pre, dtype = f"a{c}", str(g[f"a{c}_dtype"])
+        shape, ashape = tuple(int(x) for x in g[f"{pre}_shape"]), tuple(int(x) for x in g[f"{pre}_alpha_shape"])
+        a, b = (dev(g[f"{pre}_{n}"], dtype).reshape(shape) for n in "ab")
+        alpha = torch.from_numpy(f32_from_bits(g[f"{pre}_alpha"]).reshape(ashape).copy())          # a CPU tensor, as the reference passes it
+        assert_f32_bits(amd.weighted_sum(a, b, alpha), g[f"{pre}_wsum"], f"{pre} wsum")
+        assert_f32_bits(amd.add_difference(a, b, alpha), g[f"{pre}_adddiff"], f"{pre} adddiff")
+    rng = np.random.default_rng(5)
+    n = 3 * 1024 * 1024 + 5
+    a32 = oracle.to_f32(oracle.from_f32(rng.normal(0, 0.02, size=n).astype(np.float32), "bfloat16"), "bfloat16")
+    b32 = oracle.to_f32(oracle.from_f32(rng.normal(0, 0.02, size=n).astype(np.float32), "bfloat16"), "bfloat16")
+    w = rng.uniform(-0.5, 1.5, size=n).astype(np.float32)
+    ta, tb = (torch.from_numpy(x).cuda().to(torch.bfloat16) for x in (a32, b32))
+    tw = torch.from_numpy(w).cuda()
+    for out_dtype, name in ((torch.float32, "float32"), (torch.bfloat16, "bfloat16")):
+        got = host_bits(amd.weighted_sum(ta, tb, tw, out_dtype=out_dtype)).reshape(-1)
+        want = oracle.from_f32(oracle.weighted_sum(a32, b32, w), name)
+        assert np.array_equal(got, want.view(got.dtype).reshape(-1)), ("wsum", name)
+        got = host_bits(amd.add_difference(ta, tb, tw, out_dtype=out_dtype)).reshape(-1)
+        want = oracle.from_f32(oracle.add_difference(a32, b32, w), name)
+        assert np.array_equal(got, want.view(got.dtype).reshape(-1)), ("adddiff", name)
+    with pytest.raises(ValueError):
+        amd.weighted_sum(ta[:8], tb[:8], torch.ones(3, 8))                 # would broadcast the KEY, not the weights
+
+
 def test_golden_reductions(amd, oracle):
     g = load_golden("streaming")
     for c in range(int(g["n_cases"])):
