@@ -297,3 +297,16 @@ def test_rotate_recipe_takes_the_batched_plan(toy_models, tmp_path):
         y = O.to_f32(g[f"e_m1_{k}"], "bfloat16").reshape(shape)
         want = O.rotate(x, y, alignment=1.0, alpha=0.25, centralization=1.0)
         assert np.allclose(res[k].numpy(), want, rtol=0, atol=1e-6 * max(1.0, float(np.abs(want).max()))), k
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (how the driver starts it) must start its own two ranks -- as a CHILD
+    process, before anything touches a GPU -- which rendezvous and report.  --rehearse: over gloo, no GPU work."""
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse"], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rehearsal"] and line["n_gpus"] == 2
+    assert sorted((r["rank"], r["local_rank"]) for r in line["ranks"]) == [(0, 0), (1, 1)]
