@@ -900,13 +900,52 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
 //     count = (vote * elected + kept) / 2, kept counted by the filter's own compare (elected = 0: every selected value is a
 //     zero, the quotient is +0 or 0 * inf = NaN -> 0, like the reference's 0 / count);
 //   * subtraction, sums and the finishing fmas on two values per instruction (v_pk_add_f32 / v_pk_fma_f32).
-template <int DT>
-__device__ __forceinline__ void unpack_pairs(u32x4 r, f32x2 (&v)[4]) {
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+// E elements of 16-bit storage per lane: 8 (one 16-byte access) or 4 (one 8-byte access)
+template <int E> struct RawWords { uint32_t w[E / 2]; };
+template <int E>
+__device__ __forceinline__ RawWords<E> load_words_nt(const uint16_t *ptr) {
+    RawWords<E> r;
+    if constexpr (E == 8) {
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ptr));
+        r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w;
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(ptr));
+        r.w[0] = t.x; r.w[1] = t.y;
+    }
+    return r;
+}
+template <int DT, int E>
+__device__ __forceinline__ void unpack_pairs(const RawWords<E> &r, f32x2 (&v)[E / 2]) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if constexpr (DT == MECHA_BF16) v[q] = f32x2{__uint_as_float(w[q] << 16), __uint_as_float(w[q] & 0xffff0000u)};
-        else v[q] = f32x2{f16_bits_to_f32(w[q] & 0xffffu), f16_bits_to_f32(w[q] >> 16)};
+    for (int q = 0; q < E / 2; q++) {
+        if constexpr (DT == MECHA_BF16) v[q] = f32x2{__uint_as_float(r.w[q] << 16), __uint_as_float(r.w[q] & 0xffff0000u)};
+        else v[q] = f32x2{f16_bits_to_f32(r.w[q] & 0xffffu), f16_bits_to_f32(r.w[q] >> 16)};
+    }
+}
+template <int ODT, int E>
+__device__ __forceinline__ void store_words_nt(void *out, int64_t e, const float (&r)[E]) {
+    if constexpr (ODT == MECHA_F32) {
+#pragma unroll
+        for (int h = 0; h < E / 4; h++) {
+            const f32x4 v = {r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(static_cast<float *>(out) + e) + h);
+        }
+    } else {
+        uint32_t w[E / 2];
+#pragma unroll
+        for (int q = 0; q < E / 2; q++) {
+            if constexpr (ODT == MECHA_BF16) w[q] = f32_to_bf16_bits(r[2 * q]) | (f32_to_bf16_bits(r[2 * q + 1]) << 16);
+            else w[q] = f32_to_f16_bits(r[2 * q]) | (f32_to_f16_bits(r[2 * q + 1]) << 16);
+        }
+        if constexpr (E == 8) {
+            const u32x4 v = {w[0], w[1], w[2], w[3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(static_cast<uint16_t *>(out) + e));
+        } else {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = {w[0], w[1]};
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(out) + e));
+        }
     }
 }
 // clamp to [-1, 1]: the sign of an integer, or of a float's bit pattern (no -0 here).  As inline assembly: written as min(max())
@@ -917,16 +956,21 @@ __device__ __forceinline__ int sign_i32(int v) {
     return r;
 }
 
-template <int N, int DT, int ODT>
+// E: elements per lane.  8 (16-byte accesses) up to 4 deltas; 4 (8-byte accesses) for 5..8 deltas: with 8 elements the state of 8
+// input streams costs 180-228 VGPRs (2 waves per SIMD, 0.61 of 8 TB/s on the FLUX x8 stripe) whatever the source order -- the
+// scheduler hoists every model's unpack and subtraction to the front; half the elements is half the registers.
+template <int N, int DT, int ODT, int E>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
-    // FLAT grid: one block per HALF tile (256 lanes x one 16-byte vector position), no loop -- a wave loads, stores and ends.
+    constexpr int P = E / 2;                       // pairs per lane
+    constexpr int BLOCKS_PER_TILE = TIES_TILE / (MECHA_BLOCK * E);
+    // FLAT grid: one block per 256 lanes x E elements (half a tile at E = 8), no loop -- a wave loads, stores and ends.
     // Loads and stores share gfx9's one in-order vmcnt counter, so a looping wave waits for its previous stores whenever it
     // waits for its next loads; with a write stream every looped shape stops at 5.1-5.2 TB/s where this one reaches 6.0
     // (tools/stream_bench3.hip, profiles/r02_stream_bench3.txt).  The block finds its tile through one 16-byte record.
     __shared__ float recip[16];                    // correctly rounded 1 / count, [0] = +inf
     if (threadIdx.x < 16) recip[threadIdx.x] = 1.0f / (float)threadIdx.x;
-    const long long t = (long long)(blockIdx.x >> 1);
-    const int u = (int)(blockIdx.x & 1);
+    const long long t = (long long)(blockIdx.x / BLOCKS_PER_TILE);
+    const int u = (int)(blockIdx.x % BLOCKS_PER_TILE);
     TileRec rec;
     if (p.tile_rec != nullptr) rec = p.tile_rec[t];
     else {
@@ -934,13 +978,13 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
         rec = TileRec{t * TIES_TILE, 0, (int)(left < TIES_TILE ? left : TIES_TILE)};
     }
     if (rec.valid < TIES_TILE) return;                                                 // ties_merge_kernel's tile
-    const int64_t e = rec.elem + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
+    const int64_t e = rec.elem + (int64_t)u * (MECHA_BLOCK * E) + (int64_t)threadIdx.x * E;
     const uint16_t *base = static_cast<const uint16_t *>(p.base);
     // every load is issued before the key's thresholds (a second, dependent read) are needed
-    u32x4 rv[N];
-    const u32x4 rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + e));
+    RawWords<E> rv[N];
+    const RawWords<E> rb = load_words_nt<E>(base + e);
 #pragma unroll
-    for (int m = 0; m < N; m++) rv[m] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(p.in[m]) + e));
+    for (int m = 0; m < N; m++) rv[m] = load_words_nt<E>(static_cast<const uint16_t *>(p.in[m]) + e);
     float thr[N], amb_hi[N];
     bool key_ok = true, any_amb = false;
     {
@@ -959,35 +1003,35 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
     const f32x2 alpha2 = {x.alpha, x.alpha};
     {
         {
-            f32x2 b2[4];
-            unpack_pairs<DT>(rb, b2);
+            f32x2 b2[P];
+            unpack_pairs<DT, E>(rb, b2);
             f32x2 poison = zero2;                  // fma(x, 0, poison): 0 while every input is finite, NaN after inf / NaN
 #pragma unroll
-            for (int q = 0; q < 4; q++) poison = __builtin_elementwise_fma(b2[q], zero2, poison);
-            int kept[8];
+            for (int q = 0; q < P; q++) poison = __builtin_elementwise_fma(b2[q], zero2, poison);
+            int kept[E];
 #pragma unroll
-            for (int j = 0; j < 8; j++) kept[j] = 0;
+            for (int j = 0; j < E; j++) kept[j] = 0;
             bool hit = false;
-            f32x2 acc[4];
-            int cnt[8];
-            if constexpr (N <= 4) {
+            f32x2 acc[P];
+            int cnt[E];
+            if constexpr (N <= 4 || E == 4) {
                 // one sweep: the filtered deltas and their signs stay in registers
-                float f[N][8];
-                int sgn[N][8];
+                float f[N][E];
+                int sgn[N][E];
 #pragma unroll
                 for (int m = 0; m < N; m++) {
-                    f32x2 v2[4];
-                    unpack_pairs<DT>(rv[m], v2);
+                    f32x2 v2[P];
+                    unpack_pairs<DT, E>(rv[m], v2);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) poison = __builtin_elementwise_fma(v2[q], zero2, poison);
+                    for (int q = 0; q < P; q++) poison = __builtin_elementwise_fma(v2[q], zero2, poison);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) v2[q] = v2[q] - b2[q];                     // subtract (linear.py:101)
+                    for (int q = 0; q < P; q++) v2[q] = v2[q] - b2[q];                     // subtract (linear.py:101)
                     if (any_amb && amb_hi[m] >= 0.0f) {                                    // wave-uniform and rare
 #pragma unroll
-                        for (int j = 0; j < 8; j++) hit |= (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
+                        for (int j = 0; j < E; j++) hit |= (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
+                    for (int j = 0; j < E; j++) {
                         const float d = v2[j >> 1][j & 1];
                         const bool keep = __builtin_fabsf(d) >= thr[m];                    // filter_top_k (ties.py:128-132)
                         kept[j] += keep ? 1 : 0;
@@ -996,7 +1040,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < P; q++) {
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int j = 2 * q + h;
@@ -1014,23 +1058,23 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                 }
             } else {
                 // 5..8 models: two sweeps over the raw words (4 registers per model instead of 16 for delta and sign)
-                int vote[8], fs[8];
+                int vote[E], fs[E];
 #pragma unroll
-                for (int j = 0; j < 8; j++) vote[j] = 0;
+                for (int j = 0; j < E; j++) vote[j] = 0;
 #pragma unroll
                 for (int m = 0; m < N; m++) {
-                    f32x2 v2[4];
-                    unpack_pairs<DT>(rv[m], v2);
+                    f32x2 v2[P];
+                    unpack_pairs<DT, E>(rv[m], v2);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) poison = __builtin_elementwise_fma(v2[q], zero2, poison);
+                    for (int q = 0; q < P; q++) poison = __builtin_elementwise_fma(v2[q], zero2, poison);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) v2[q] = v2[q] - b2[q];
+                    for (int q = 0; q < P; q++) v2[q] = v2[q] - b2[q];
                     if (any_amb && amb_hi[m] >= 0.0f) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) hit |= (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
+                        for (int j = 0; j < E; j++) hit |= (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
+                    for (int j = 0; j < E; j++) {
                         const float d = v2[j >> 1][j & 1];
                         const bool keep = __builtin_fabsf(d) >= thr[m];
                         kept[j] += keep ? 1 : 0;
@@ -1038,20 +1082,20 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < E; j++) {
                     fs[j] = sign_i32(vote[j]);
                     cnt[j] = (vote[j] * fs[j] + kept[j]) >> 1;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] = zero2;
+                for (int q = 0; q < P; q++) acc[q] = zero2;
 #pragma unroll
                 for (int m = 0; m < N; m++) {
-                    f32x2 v2[4];
-                    unpack_pairs<DT>(rv[m], v2);
+                    f32x2 v2[P];
+                    unpack_pairs<DT, E>(rv[m], v2);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) v2[q] = v2[q] - b2[q];
+                    for (int q = 0; q < P; q++) v2[q] = v2[q] - b2[q];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < P; q++) {
                         f32x2 g;
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
@@ -1064,9 +1108,9 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                     }
                 }
             }
-            f32x2 r2[4];
+            f32x2 r2[P];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < P; q++) {
                 // filtered_delta / param_counts (ties.py:124), correctly rounded: y = RN(1 / count), q0 = RN(a y),
                 // q = RN(q0 + (a - count q0) y)  (see ties_merge_kernel)
                 const f32x2 y = {recip[cnt[2 * q]], recip[cnt[2 * q + 1]]};
@@ -1079,11 +1123,21 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
             }
             f32x2 out_poison = zero2;
 #pragma unroll
-            for (int q = 0; q < 4; q++) out_poison = __builtin_elementwise_fma(r2[q], zero2, out_poison);
-            const float r[8] = {r2[0].x, r2[0].y, r2[1].x, r2[1].y, r2[2].x, r2[2].y, r2[3].x, r2[3].y};
-            store8<ODT, true>(out, e, r);
+            for (int q = 0; q < P; q++) out_poison = __builtin_elementwise_fma(r2[q], zero2, out_poison);
+            float r[E];
+#pragma unroll
+            for (int q = 0; q < P; q++) { r[2 * q] = r2[q].x; r[2 * q + 1] = r2[q].y; }
+            store_words_nt<ODT, E>(out, e, r);
             const bool bad = (poison.x != poison.x) | (poison.y != poison.y);
             const bool bad_o = (out_poison.x != out_poison.x) | (out_poison.y != out_poison.y);
+            if constexpr (E == 4) {
+                // the hit queue holds 8-element vectors (ties_amb_collect_kernel scans 8 from the recorded element): a lane pair
+                // shares one, recorded once by its even lane (whose element index is a multiple of 8)
+                if (any_amb) {
+                    const bool pair_hit = hit | (__shfl_xor((int)hit, 1, 64) != 0);
+                    hit = pair_hit && ((threadIdx.x & 1) == 0);
+                }
+            }
             if (hit) {
                 const unsigned long long slot = atomicAdd(&p.globals->n_hit, 1ull);
                 if (slot < p.amb_capacity) { p.hit_elem[slot] = e; p.hit_seg[slot] = (uint32_t)rec.seg; }
@@ -1520,10 +1574,11 @@ void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float 
 
 template <int N, int DT>
 void launch_merge_full(const TiesParams &p, const MergeExtra &x, unsigned /*looped_grid*/, void *out, uint32_t *flags, hipStream_t s) {
-    const unsigned grid = (unsigned)(2 * p.total_tiles);          // flat: one block per half tile
-    if (p.out_dt == MECHA_BF16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_BF16>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
-    else if (p.out_dt == MECHA_F16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F16>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
-    else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F32>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    constexpr int E = N <= 4 ? 8 : 4;                             // elements per lane (see the kernel)
+    const unsigned grid = (unsigned)(p.total_tiles * (TIES_TILE / (MECHA_BLOCK * E)));          // flat: one block per 256 x E elements
+    if (p.out_dt == MECHA_BF16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_BF16, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    else if (p.out_dt == MECHA_F16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F16, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F32, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
 }
 
 template <bool DARE>
