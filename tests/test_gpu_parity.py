@@ -522,3 +522,54 @@ def test_full_size_properties(amd):
     for m, t in zip((b, c), thr):
         dm = (m.float() - a.float()).abs()
         assert int((dm < t).sum().item()) < kth <= int((dm <= t).sum().item())
+
+
+def test_full_config2_job_sampled_keys_vs_oracle(amd, oracle):
+    """BASELINE config 2 at FULL size -- every key of an SDXL-shaped checkpoint x4 (2 529 keys, 3.47 B elements per model) in ONE
+    batched launch sequence, as bench.py and merge() run it -- checked where the oracle can follow: the thresholds of EVERY
+    (key, delta) pair by their rank property (the kth-smallest |delta|, counted with torch on the device), and the output and
+    flag word of a spread of keys (largest, smallest, ragged tails, the keys around them in the arena) bit for bit."""
+    import ctypes
+    import pathlib
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    import bench
+    from sd_mecha_amd import _lib
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip("needs 60 GB of free HBM")
+    job = bench.Job("sdxl_ties", 0, torch.device("cuda", 0))
+    L, lib = job.layout, job.lib
+    n_keys, nd = len(L.keys), job.n_models - 1
+    thr = torch.zeros((n_keys, nd), dtype=torch.float32, device="cuda")
+    job.flags.zero_()
+    st = lib.mecha_batched_add_difference_ties(
+        job.arenas[0].data_ptr(), job.model_ptrs, nd, job.out.data_ptr(), job.segs_dev.data_ptr(), ctypes.addressof(job.segs_host), n_keys,
+        L.total_elems, _lib.BF16, _lib.BF16, 0.2, 1.0, 0, thr.data_ptr(), job.ws.data_ptr(), job.ws.numel(), job.flags.data_ptr(),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(st, "batched ties")
+    torch.cuda.synchronize()
+    assert int(job.flags.abs().sum().item()) == 0
+    # rank property of every threshold (ties.py:128-132): #(|d| < t) < kth <= #(|d| <= t)
+    base = job.arenas[0]
+    bad = []
+    for i, (o, n) in enumerate(zip(L.offsets, L.numels)):
+        kth = max(int((1 - 0.2) * n), 1)
+        b32 = base[o:o + n].float()
+        for d in range(nd):
+            dm = (job.arenas[1 + d][o:o + n].float() - b32).abs()
+            t = thr[i, d]
+            if not (int((dm < t).sum().item()) < kth <= int((dm <= t).sum().item())):
+                bad.append((L.keys[i], d))
+    assert not bad, bad[:5]
+    # outputs of a spread of keys against the oracle
+    order = sorted(range(n_keys), key=lambda i: L.numels[i])
+    picks = set(order[:6] + order[-3:] + order[len(order) // 2 - 3:len(order) // 2 + 3] + [i for i in range(n_keys) if L.numels[i] % 4096][:6])
+    for i in sorted(picks):
+        o, n = L.offsets[i], L.numels[i]
+        bits = [host_bits(a[o:o + n]) for a in job.arenas]
+        b32 = oracle.to_f32(bits[0], "bfloat16")
+        deltas = [oracle.subtract(oracle.to_f32(x, "bfloat16"), b32) for x in bits[1:]]
+        want, det = oracle.ties_sum(deltas, k=0.2, details=True)
+        assert np.array_equal(host_bits(thr[i]), det["thresholds"].view(np.uint32)), (L.keys[i], "thresholds")
+        assert np.array_equal(host_bits(job.out[o:o + n]), oracle.from_f32(oracle.add_difference(b32, want, 1.0), "bfloat16")), (L.keys[i], n, "output")
