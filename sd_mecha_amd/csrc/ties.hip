@@ -205,85 +205,6 @@ __device__ __forceinline__ unsigned long long ties_kth(double one_minus_k, int64
     return (unsigned long long)(kth < 1 ? 1 : kth);
 }
 
-// ------------------------------------------------------------------------------------------------ A: sample
-// One workgroup per (key, delta): sort TIES_SAMPLE sampled |delta| bit patterns, derive the bracket.
-__global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, double one_minus_k, float *thresholds_out) {
-    __shared__ uint32_t keys[TIES_SAMPLE];
-    const int64_t sd = blockIdx.x;
-    const int s = (int)(sd / p.n_deltas), d = (int)(sd % p.n_deltas);
-    const mecha_segment seg = get_segment(p, s);
-    const bool whole = seg.numel <= TIES_SAMPLE;
-    if (whole) {
-        for (int idx = threadIdx.x; idx < TIES_SAMPLE; idx += MECHA_BLOCK) {
-            uint32_t bits = 0xffffffffu;                                  // padding sorts last
-            if (idx < seg.numel) {
-                float x = load1_rt(p.in_dt, p.in[d], seg.offset + idx);
-                if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, seg.offset + idx);
-                bits = __float_as_uint(x) & 0x7fffffffu;
-            }
-            keys[idx] = bits;
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int vpos = 2 * threadIdx.x + u;                         // 512 stratified runs of 8 contiguous elements
-            const int64_t local = (int64_t)(((unsigned long long)vpos * (unsigned long long)seg.numel) / 512ull) & ~7ll;
-            const int64_t e = seg.offset + local;
-            float v[8], b[8];
-            load_rt(p.in_dt, p.vec_ok != 0, p.in[d], e, 8, v);
-            if (p.base != nullptr) {
-                load_rt(p.in_dt, p.vec_ok != 0, p.base, e, 8, b);
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) keys[vpos * 8 + j] = __float_as_uint(v[j]) & 0x7fffffffu;
-        }
-    }
-    __syncthreads();
-    for (int k = 2; k <= TIES_SAMPLE; k <<= 1) {                          // bitonic sort, ascending
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int idx = threadIdx.x; idx < TIES_SAMPLE; idx += MECHA_BLOCK) {
-                const int ixj = idx ^ j;
-                if (ixj > idx) {
-                    const uint32_t a = keys[idx], b = keys[ixj];
-                    const bool up = (idx & k) == 0;
-                    if ((a > b) == up) { keys[idx] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (threadIdx.x == 0) {
-        SelectState st{};
-        st.kth = ties_kth(one_minus_k, seg.numel);
-        if (whole) {
-            st.mode = MODE_RESOLVED;
-            st.threshold_bits = keys[st.kth - 1];
-            if (thresholds_out != nullptr) thresholds_out[sd] = __uint_as_float(st.threshold_bits);
-        } else {
-            const double q = ((double)st.kth - 0.5) / (double)seg.numel;
-            const double r = q * TIES_SAMPLE;
-            const double margin = 6.0 * sqrt(TIES_SAMPLE * q * (1.0 - q)) + 16.0;
-            const long long lo_rank = (long long)floor(r - margin), hi_rank = (long long)ceil(r + margin);
-            st.mode = MODE_PENDING;
-            st.lo = (lo_rank < 0) ? 0u : keys[lo_rank];
-            st.hi = (hi_rank >= TIES_SAMPLE) ? 0x7f800000u : keys[hi_rank];
-            if (st.hi > 0x7f800000u) st.hi = 0x7f800000u;                 // NaN patterns stay above every bracket
-            if (st.lo > st.hi) st.lo = st.hi;
-            // bins over lo <= bits <= hi, see bracket_bin(): 1024 cells of 2^shift patterns, two bins per cell
-            const uint32_t span = st.hi - st.lo;
-            st.shift = (span >= 1024u) ? (uint32_t)(32 - __clz((int)span)) - 10u : 0u;      // span < 2^(shift + 10)
-            st.lo = (st.lo >> st.shift) << st.shift;                      // cells start at lo
-            const unsigned long long top = ((((unsigned long long)(st.lo >> st.shift)) + 1024ull) << st.shift) - 1ull;
-            if (top < st.hi) st.hi = (uint32_t)top;                       // trims less than one cell off the bracket
-        }
-        p.state[sd] = st;
-        p.counts[sd] = SelectCounts{0ull, 0ull};
-        p.fill[sd] = 0u;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ A: count
 // Bin of a bit pattern inside the bracket (lo <= bits <= hi).  The bracket is cut into 1024 cells of 2^shift patterns,
 // aligned to absolute multiples of 2^shift.  Each cell owns two bins, in value order: bin 2q holds the one pattern
@@ -463,6 +384,109 @@ __device__ __forceinline__ void find_bin(const uint32_t *h, unsigned long long r
     }
     __syncthreads();
     bin_out = *sel; below_out = *sel_below; count_out = *sel_count;
+}
+
+// ------------------------------------------------------------------------------------------------ A: sample
+// Value of 0-indexed rank `rank` among the block's 4096 sampled bit patterns (16 per thread, in registers; 0xffffffff = padding,
+// never selected: ranks stay below the number of real samples): MSD radix select in three passes of 11 / 11 / 9 bits through one
+// 2048-bin LDS histogram.  Replaces a bitonic sort of the 4096 patterns in LDS (78 compare-exchange stages with a barrier each:
+// 0.75 ms for the 7 587 (key, delta) pairs of the SDXL x4 job, VALU- and LDS-issue-bound) -- only two order statistics are needed.
+__device__ __forceinline__ uint32_t sample_select(const uint32_t (&k)[16], uint32_t rank, uint32_t *hist, unsigned long long *wave_tot, int *sel,
+                                                  unsigned long long *sel_below, uint32_t *sel_count) {
+    uint32_t prefix = 0u, mask = 0x80000000u;
+    unsigned long long r = (unsigned long long)rank + 1ull;              // find_bin takes 1-indexed ranks
+    const int shifts[3] = {20, 9, 0};
+    const uint32_t nbins[3] = {2048u, 2048u, 512u};
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++) {
+        for (int i = threadIdx.x; i < TIES_BINS; i += MECHA_BLOCK) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if ((k[i] & mask) == prefix) atomicAdd(&hist[(k[i] >> shifts[pass]) & (nbins[pass] - 1u)], 1u);
+        __syncthreads();
+        int bin; unsigned long long below; uint32_t count;
+        find_bin(hist, r, bin, below, count, wave_tot, sel, sel_below, sel_count);
+        if (bin < 0) bin = 0;                                            // cannot happen: rank < number of samples under the prefix
+        prefix |= (uint32_t)bin << shifts[pass];
+        mask |= (nbins[pass] - 1u) << shifts[pass];
+        r -= below;
+        __syncthreads();                                                 // find_bin's shared words are reused by the next pass
+    }
+    return prefix;
+}
+
+// One workgroup per (key, delta): TIES_SAMPLE sampled |delta| bit patterns, the bracket from two of their order statistics.
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, double one_minus_k, float *thresholds_out) {
+    __shared__ uint32_t hist[TIES_BINS];
+    __shared__ unsigned long long wave_tot[MECHA_BLOCK / 64];
+    __shared__ int sel;
+    __shared__ unsigned long long sel_below;
+    __shared__ uint32_t sel_count;
+    const int64_t sd = blockIdx.x;
+    const int s = (int)(sd / p.n_deltas), d = (int)(sd % p.n_deltas);
+    const mecha_segment seg = get_segment(p, s);
+    const bool whole = seg.numel <= TIES_SAMPLE;
+    uint32_t k[16];
+    if (whole) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx = threadIdx.x + i * MECHA_BLOCK;
+            uint32_t bits = 0xffffffffu;                                  // padding: beyond every rank
+            if (idx < seg.numel) {
+                float x = load1_rt(p.in_dt, p.in[d], seg.offset + idx);
+                if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, seg.offset + idx);
+                bits = __float_as_uint(x) & 0x7fffffffu;
+            }
+            k[i] = bits;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int vpos = 2 * threadIdx.x + u;                         // 512 stratified runs of 8 contiguous elements
+            const int64_t local = (int64_t)(((unsigned long long)vpos * (unsigned long long)seg.numel) / 512ull) & ~7ll;
+            const int64_t e = seg.offset + local;
+            float v[8], b[8];
+            load_rt(p.in_dt, p.vec_ok != 0, p.in[d], e, 8, v);
+            if (p.base != nullptr) {
+                load_rt(p.in_dt, p.vec_ok != 0, p.base, e, 8, b);
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) k[u * 8 + j] = __float_as_uint(v[j]) & 0x7fffffffu;
+        }
+    }
+    // block-uniform: every thread derives the same ranks
+    SelectState st{};
+    st.kth = ties_kth(one_minus_k, seg.numel);
+    if (whole) {
+        const uint32_t t = sample_select(k, (uint32_t)(st.kth - 1), hist, wave_tot, &sel, &sel_below, &sel_count);
+        st.mode = MODE_RESOLVED;
+        st.threshold_bits = t;
+        if (threadIdx.x == 0 && thresholds_out != nullptr) thresholds_out[sd] = __uint_as_float(t);
+    } else {
+        const double q = ((double)st.kth - 0.5) / (double)seg.numel;
+        const double r = q * TIES_SAMPLE;
+        const double margin = 6.0 * sqrt(TIES_SAMPLE * q * (1.0 - q)) + 16.0;
+        const long long lo_rank = (long long)floor(r - margin), hi_rank = (long long)ceil(r + margin);
+        st.mode = MODE_PENDING;
+        st.lo = (lo_rank < 0) ? 0u : sample_select(k, (uint32_t)lo_rank, hist, wave_tot, &sel, &sel_below, &sel_count);
+        st.hi = (hi_rank >= TIES_SAMPLE) ? 0x7f800000u : sample_select(k, (uint32_t)hi_rank, hist, wave_tot, &sel, &sel_below, &sel_count);
+        if (st.hi > 0x7f800000u) st.hi = 0x7f800000u;                     // NaN patterns stay above every bracket
+        if (st.lo > st.hi) st.lo = st.hi;
+        // bins over lo <= bits <= hi, see bracket_bin(): 1024 cells of 2^shift patterns, two bins per cell
+        const uint32_t span = st.hi - st.lo;
+        st.shift = (span >= 1024u) ? (uint32_t)(32 - __clz((int)span)) - 10u : 0u;      // span < 2^(shift + 10)
+        st.lo = (st.lo >> st.shift) << st.shift;                          // cells start at lo
+        const unsigned long long top = ((((unsigned long long)(st.lo >> st.shift)) + 1024ull) << st.shift) - 1ull;
+        if (top < st.hi) st.hi = (uint32_t)top;                           // trims less than one cell off the bracket
+    }
+    if (threadIdx.x == 0) {
+        p.state[sd] = st;
+        p.counts[sd] = SelectCounts{0ull, 0ull};
+        p.fill[sd] = 0u;
+    }
 }
 
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_resolve_kernel(TiesParams p, float *thresholds_out, int force_fail) {
@@ -732,8 +756,13 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
             }
         }
         const mecha_segment seg = cur.seg;
-        // the same test as in ties_merge_full_kernel: that kernel merges this tile
-        if (x.skip_full_tiles && in_regs && fast_div && (t - cur.first + 1) * TIES_TILE <= seg.numel) continue;
+        // the same test as in ties_merge_full_kernel: that kernel merges every full tile of this key.  Only the key's last tile can
+        // be ragged: the walk jumps to it (or past the key) instead of visiting 400 full tiles per block one by one
+        if (x.skip_full_tiles && in_regs && fast_div) {
+            const long long last = cur.end - 1;
+            const bool last_ragged = (cur.end - cur.first) * TIES_TILE > seg.numel;
+            if (t < last || !last_ragged) { t = (last_ragged ? last : cur.end) - 1; continue; }
+        }
 #pragma unroll 1
         for (int u = 0; u < 2; u++) {
             const int64_t local = (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
@@ -1150,12 +1179,17 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
 
 // ------------------------------------------------------------------------------------------------ A: select + fixup
 // One block per ambiguous pair: exact radix select (11 / 11 / 10 bits) of rank amb_rank inside its list.
-__global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_select_kernel(TiesParams p, float *thresholds_out) {
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_select_kernel(TiesParams p, float *thresholds_out, int64_t n_sd) {
     __shared__ uint32_t hist[TIES_BINS];
     __shared__ uint32_t s_prefix, s_rank;
-    const int64_t sd = blockIdx.x;
+    __shared__ unsigned long long wave_tot[MECHA_BLOCK / 64];
+    __shared__ int sel;
+    __shared__ unsigned long long sel_below;
+    __shared__ uint32_t sel_count;
+    // a few hundred blocks walk the pairs (ambiguous ones are rare: a block per pair spent 0.14 ms on 7 587 early exits)
+    for (int64_t sd = blockIdx.x; sd < n_sd; sd += gridDim.x) {
     const SelectState st = p.state[sd];
-    if (st.mode != MODE_AMBIG) return;
+    if (st.mode != MODE_AMBIG) continue;                                  // block-uniform
     const uint32_t n = p.fill[sd] < st.amb_count ? p.fill[sd] : st.amb_count;
     const uint32_t *bits = p.amb_bits + st.amb_offset;
     if (threadIdx.x == 0) { s_prefix = 0; s_rank = st.amb_rank; }
@@ -1171,21 +1205,23 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_select_kernel(TiesParams
             if ((b & masks[pass]) == prefix) atomicAdd(&hist[(b >> shifts[pass]) & (nbins[pass] - 1u)], 1u);
         }
         __syncthreads();
+        // (the scan over the bins by the whole block: one thread walking 2048 bins three times took 0.1 ms per pair)
+        int bin; unsigned long long below; uint32_t count;
+        const uint32_t rank = s_rank;
+        find_bin(hist, (unsigned long long)rank, bin, below, count, wave_tot, &sel, &sel_below, &sel_count);
+        if (bin < 0) { bin = (int)nbins[pass] - 1; below = 0; }               // rank beyond the list (cannot happen): the old scan's last bin
+        __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t cum = 0, rank = s_rank, bin = 0;
-            for (uint32_t k = 0; k < nbins[pass]; k++) {
-                if (rank <= cum + hist[k]) { bin = k; break; }
-                cum += hist[k];
-                bin = k;
-            }
-            s_prefix = prefix | (bin << shifts[pass]);
-            s_rank = rank - cum;
+            s_prefix = prefix | ((uint32_t)bin << shifts[pass]);
+            s_rank = rank - (uint32_t)below;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         p.state[sd].threshold_bits = s_prefix;
         if (thresholds_out != nullptr) thresholds_out[sd] = __uint_as_float(s_prefix);
+    }
+    __syncthreads();                                                      // s_prefix / s_rank are rewritten for the next pair
     }
 }
 
@@ -1752,7 +1788,7 @@ int run_ties(const TiesCall &c) {
         launch_merge<false>(p, x, grid, c.out, c.flags, s);
         if (need_count) {
             MECHA_LAUNCH(MK_TIES_FIXUP, ties_amb_collect_kernel, dim3(64), dim3(MECHA_BLOCK), 0, s, p);
-            MECHA_LAUNCH(MK_TIES_FIXUP, ties_amb_select_kernel, dim3((unsigned)n_sd), dim3(MECHA_BLOCK), 0, s, p, c.thresholds_out);
+            MECHA_LAUNCH(MK_TIES_FIXUP, ties_amb_select_kernel, dim3((unsigned)(n_sd < 512 ? n_sd : 512)), dim3(MECHA_BLOCK), 0, s, p, c.thresholds_out, (int64_t)n_sd);
             MECHA_LAUNCH(MK_TIES_FIXUP, ties_fixup_kernel, dim3(256), dim3(MECHA_BLOCK), 0, s, p, x, c.out, c.flags);
         }
     }
