@@ -381,9 +381,10 @@ def main():
         # HBM bytes per launch from the PMC counters: they need rocprofv3, so they are collected in separate runs of this
         # same command and committed under profiles/ (how: the file's "_how"); None when this workload was not measured
         traffic = None
-        traffic_file = pathlib.Path(__file__).resolve().parent / "profiles" / "r01_hbm_traffic.json"
-        if traffic_file.exists():
-            traffic = json.loads(traffic_file.read_text()).get(args.workload, {}).get(dom, {}).get("hbm_bytes_per_launch")
+        for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):          # the newest collection that covers this kernel
+            traffic_file = pathlib.Path(__file__).resolve().parent / "profiles" / name
+            if traffic is None and traffic_file.exists():
+                traffic = json.loads(traffic_file.read_text()).get(args.workload, {}).get(dom, {}).get("hbm_bytes_per_launch")
         line = {
             "metric": "merged state-dict GB/s", "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True,

@@ -56,7 +56,7 @@ def main():
         manifest = [(k, s, d) for k, s, d in load_manifest("sd1-ldm") if d.startswith("float") and not k.startswith("model_ema.")]
         n_models, dtype = 2, torch.float16
     elif args.config in ("3n", "3t"):
-        manifest = [(k, s, d) for k, s, d in load_manifest("flux-flux", ("diffuser",)) if d.startswith("float")]
+        manifest = [(k, s, d) for k, s, d in load_manifest("flux-flux", ("diffuser",)) if not d.startswith("int")]
         n_models, dtype = 8, torch.bfloat16
     elif args.config == "5":
         manifest = [(k, s, d) for k, s, d in load_manifest("sdxl-kohya") if d.startswith("float")]
@@ -104,7 +104,9 @@ def main():
                 k["disable"] = True
                 super().__init__(*a, **k)
 
-        rm = [sd_mecha.model(p, config="sdxl-kohya") if n_loras else sd_mecha.model(p) for p in paths]
+        # a key subset is too small for the reference's config inference: name the config
+        ref_config = {"1": "sd1-ldm", "2": "sdxl-sgm", "3n": "flux-flux", "3t": "flux-flux", "4": "sdxl-sgm", "5": "sdxl-kohya"}[args.config]
+        rm = [sd_mecha.model(p, config=ref_config) for p in paths]
         if args.config == "1":
             ref_recipe = linear.weighted_sum(rm[0], rm[1], alpha=0.5)
         elif args.config == "3n":
