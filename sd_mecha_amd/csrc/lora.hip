@@ -621,6 +621,8 @@ __device__ __forceinline__ void lora_tile_general(const LoraParams &p, const mec
 // (every later access is an LDS read: a global load inside the k-loop would have to wait out the LDS-DMA ring, vmcnt is
 // in order) and the same threads evaluate the fast / general test.
 constexpr int LORA_FAST_BLOCK = 512;            // the fast kernel: 8 waves, wave tile 32 columns x 64 rows
+// (two blocks per CU -- __launch_bounds__(512, 4): 128 VGPRs, 26 of them spilled, 2 x 65 KB of LDS -- took 13.6 ms for the SDXL x16
+//  batch against 11.5 ms with one block per CU: round 2)
 template <int LDT, bool BATCHED, bool FAST>
 __global__ __launch_bounds__(FAST ? LORA_FAST_BLOCK : MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FAST ? RING * STAGE_BYTES : 2 * SLAB_HALFS * 2];

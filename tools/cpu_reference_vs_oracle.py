@@ -64,7 +64,8 @@ def main():
     else:
         manifest = [(k, s, d) for k, s, d in load_manifest("sdxl-sgm") if d.startswith("float")]
         n_models, dtype = (4 if args.config == "2" else 2), torch.bfloat16
-    manifest = manifest[::args.stride]
+    if args.stride > 1:                                     # a spread over the key sizes, not whatever sits at every n-th position
+        manifest = sorted(manifest, key=lambda e: numel(e[1]))[args.stride // 2::args.stride]
     work = pathlib.Path(args.dir)
     work.mkdir(parents=True, exist_ok=True)
     try:
