@@ -472,14 +472,19 @@ class HipBackend:
             _lib.check(L.mecha_batched_weighted_sum(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(), segs.data_ptr(), len(flat),
                                                     layout.total_elems, in_dt, out_dt, alpha, fl_all.data_ptr(), stream), "batched lerp (rotate, ndim <= 1)")
             pos = len(flat)
+        # the calls of the wave, planned first: ONE workspace of the largest size serves them all (growing it between calls
+        # frees the old one, and a free waits for the device: the host then sits behind every queued kernel)
+        calls = []
         for (n, p), idx in groups.items():
             per_key = int(L.mecha_batched_rotate_workspace_bytes(n, p, 1))
             chunk = max(1, min(len(idx), self.ROTATE_WORKSPACE_BYTES // max(per_key, 1)))
             chunk = -(-len(idx) // -(-len(idx) // chunk))          # equal shares when the group needs several calls
+            calls.append((n, p, idx, chunk, max(int(L.mecha_batched_rotate_workspace_bytes(n, p, min(chunk, len(idx) - c0)))
+                                                   for c0 in range(0, len(idx), chunk))))
+        ws = self._rotate_ws(max((c[4] for c in calls), default=16))
+        for n, p, idx, chunk, _ in calls:
             for c0 in range(0, len(idx), chunk):
                 cnt = min(chunk, len(idx) - c0)
-                nbytes = int(L.mecha_batched_rotate_workspace_bytes(n, p, cnt))
-                ws = self._rotate_ws(nbytes)
                 _lib.check(L.mecha_batched_rotate(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(),
                                                   offs_all[pos + c0:].data_ptr(), cnt, n, p, in_dt, out_dt, float(cz), int(alignment), float(alpha),
                                                   ws.data_ptr(), ws.numel(), fl_all[pos + c0:].data_ptr(), stream), "mecha_batched_rotate")
