@@ -155,6 +155,8 @@ def main():
         worst_rel = 0.0
         for k in keys:
             x, y = a[k].view(torch.int16).numpy().astype(np.int32), b[k].view(torch.int16).numpy().astype(np.int32)
+            # sign-aware distance in units of the output dtype: map the sign-magnitude patterns onto one ordered line
+            x, y = np.where(x < 0, -(x & 0x7fff), x), np.where(y < 0, -(y & 0x7fff), y)
             d = np.abs(x - y)
             if d.size and d.max() > 0:
                 differing += 1
