@@ -174,246 +174,321 @@ __device__ __forceinline__ void load_up(const uint16_t *up, int rank, int64_t ro
 // ~250 VALU + ~170 SALU per chunk on 64-bit addresses, tail guards and the fold against 8 MFMAs (rocprofv3 PMC: 4044
 // VALU and 128 MFMA instructions per wave and tile, MFMA pipe 9 % busy).  Here:
 //   * both factors go global -> LDS with global_load_lds_dwordx4 (no registers) through a ring of RING stages, RING - 1
-//     chunks in flight per block; waves wait with a counted s_waitcnt vmcnt and meet at a raw s_barrier;
+//     chunks in flight per block; waves wait with a counted s_waitcnt vmcnt and meet at a raw s_barrier; the chunk sequence
+//     of the key (DMA base addresses, fold flags) is a table in LDS made when the block enters the key;
 //   * the LDS-DMA writes 64 lanes x 16 B contiguously, so layouts are made on the SOURCE side: the down slab keeps its
 //     256-byte rows with the four 64-byte windows of row k XOR-ed by k & 3 (the transposing reads of 4 consecutive k-rows then
 //     hit 4 different windows: conflict-free), the up slab is [k / 8][row] in 16-byte slots (a lane's B fragment is one
 //     ds_read_b128, 16 consecutive rows per lane group);
 //   * partial tiles read clamped rows / columns (the key's last row, its last 8 columns) instead of guarding every load:
 //     pad, don't mask -- only the base loads and the stores are predicated;
-//   * a network's first k-step starts from C = 0 as an inline constant; the fold is one packed fma per two accumulators
-//     when the scale is a power of two (see below);
+//   * the fold is one packed fma per two accumulators when the scale is a power of two (see below); the base tile's loads are
+//     issued behind the first stages and consumed at the first fold;
 //   * finite checks: base and output through a packed fma(x, 0, poison) (NaN iff some x is inf / NaN), factors (edge tiles
 //     only, read back from the stage) through a packed 16-bit max of the magnitudes.
 typedef uint16_t u16x8v __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+enum : int { NET_ENDS_GROUP = 2, NET_ONE_STEP = 4 };   // mecha_lora_net::reserved of the LDS copy
 constexpr int RING = 4;
-enum : int { NET_STARTS_GROUP = 1, NET_ENDS_GROUP = 2, NET_ONE_STEP = 4 };   // mecha_lora_net::reserved of the LDS copy
-constexpr int STAGE_BYTES = 16384;              // down: 32 rows x 256 B, then up: 4 k-parts x 128 rows x 16 B
-constexpr int STAGE_UP = 8192;
+constexpr int STAGE_UP = 8192;                  // down: 32 rows x 256 B, then up: 128 rows x 64 B
+constexpr int STAGE_BYTES = 16384;
+constexpr int DMA_PER_STAGE = 4;                // per wave: two 1-KiB pieces of each factor
+constexpr int MAX_CHUNKS = 128;                 // 32-deep k-chunks of one key, all networks together (beyond: the general path)
+enum : uint32_t { CH_FOLD = 1, CH_ONE_STEP = 2 };
+// One k-chunk of one network, ready for the DMA: made once per key and block (enter_key), read once per round.  The loop
+// around the MFMAs then holds no network bookkeeping: no rank compare, no 64-bit multiply, no group logic.
+struct __attribute__((aligned(16))) LoraChunk {
+    const char *down;                           // row k0 of down
+    const char *up;                             // column k0 of up
+    uint32_t rank2;                             // bytes per row of up
+    uint32_t flags;                             // CH_FOLD: the chunk closes a run of networks with equal (scale, weight)
+    float scale, weight;
+};
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
-typedef __attribute__((address_space(1))) const unsigned char global_byte;
 
-// One LDS-DMA instruction: lane l's 16 bytes at `src` go to dst + 16 l (dst wave-uniform, in M0).  Written as inline
-// assembly on purpose: for the builtin the compiler cannot tell which LDS bytes the DMA writes, so it puts s_waitcnt vmcnt(0)
-// in front of every later LDS read -- that drains the ring in every round (measured: 20.6 ms for the SDXL x16 batch, each
-// round one full L2 / HBM round trip).  Here the waits are the counted s_waitcnt vmcnt of the round itself; loads the
-// compiler does not know about only make its own waits conservative (vmcnt retires in order).
-__device__ __forceinline__ void glds16(const char *src, unsigned char *dst) {
-    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte *)dst);
-    // M0 is compiler-reserved and not preserved around an asm statement: written in the statement that reads it, and put back
+// The LDS-DMA instructions of one wave and stage: lane l's 16 bytes at `src` go to dst + 16 l (dst wave-uniform, in M0).
+// Written as inline assembly on purpose: for the builtin the compiler cannot tell which LDS bytes the DMA writes, so it puts
+// s_waitcnt vmcnt(0) in front of every later LDS read -- that drains the ring in every round.  Here the waits are the counted
+// s_waitcnt vmcnt of the round itself; loads the compiler does not know about only make its own waits conservative (vmcnt
+// retires in order).  M0 is compiler-reserved and not preserved around an asm statement: saved and put back in the statement.
+__device__ __forceinline__ void glds16x4(const char *s0, const char *s1, const char *s2, const char *s3, uint32_t down_lds, uint32_t up_lds) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+    const uint32_t d1 = down_lds + 1024u, u1 = up_lds + 1024u;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "s"(down_lds), "s"(d1), "s"(up_lds), "s"(u1) : "memory");
+}
+// s_waitcnt vmcnt(n) for the counts the rounds use (multiples of 4 up to 24)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    }
 }
 
+// Block = 4 waves, block tile 128 x 128, wave tile 64 columns x 64 rows (2 x 2 MFMA tiles: 8 MFMAs per round and wave for
+// 8 transposing reads + 4 ds_read_b128).  Two blocks per CU: one block's tile prologue / epilogue (a chain of memory
+// latencies with nothing to overlap inside the block) runs beside the other block's rounds.
+// Column permutation: the lane that gives the transposing read the address of k-row q, chunk p of a 16-lane group points at
+// columns 16 (p & 1) + 8 gbit + 4 (p >> 1) of the 32-column window instead of 16 gbit + 4 p.  MFMA row index M = 8 g + 4 h + e of
+// the accumulator layout is then output column 16 h + 4 g + e: a lane's 16 accumulators are 16 CONTIGUOUS output columns
+// (16-byte base loads and output stores), and the 32 lanes of one LDS cycle still cover each 64-byte window exactly once.
 template <int LDT>
-__device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_lora_key &key, const mecha_lora_net *nets, int key_index,
+__device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_lora_key &key, const LoraChunk *chunks, int n_chunks, int key_index,
                                                int64_t tile_x, int64_t tile_y, unsigned char *ring) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int64_t bcol0 = tile_x * LORA_TILE, brow0 = tile_y * LORA_TILE;
-    const int wcol = (wave & 3) * 32, wrow = (wave >> 2) * 64;       // wave tile: 32 columns x 64 rows (8 waves per block)
-    const int64_t row0 = brow0 + wrow + r;
+    const int wcol = (wave & 1) * 64, wrow = (wave >> 1) * 64;
     const bool check_up = tile_x == 0, check_down = tile_y == 0;
     const char *base = static_cast<const char *>(p.base);
     const int64_t last_row = key.rows - 1;
 
-    // ---- LDS-DMA source offsets of this lane (bytes).  Each wave issues one 1-KiB instruction per factor and chunk:
-    //   down: wave I fills rows 4I .. 4I+3 of the slab; lane = (row & 3) * 16 + 16-byte slot; slot s of row k holds the logical
-    //         window (s >> 2) ^ (k & 3), i.e. columns 8 * ((((s >> 2) ^ (k & 3)) << 2) | (s & 3)) .. + 7 of the tile;
-    //   up:   wave I fills slots 64I .. 64I+63 of [k-part][row]: k-part = I >> 1, rows 64 (I & 1) + lane of the tile.
+    // ---- LDS-DMA source offsets of this lane (bytes).  Piece m = 2 wave + j (j = 0, 1) of each factor:
+    //   down: rows 4m .. 4m+3 of the slab; lane = (row & 3) * 16 + 16-byte slot; slot s of row k holds the logical window
+    //         (s >> 2) ^ (k & 3), i.e. columns 8 * ((((s >> 2) ^ (k & 3)) << 2) | (s & 3)) .. + 7 of the tile;
+    //   up:   rows 16m .. 16m+15 of the tile, 64 B each (1 KiB contiguous in memory when the rank is 32: the DMA reads whole
+    //         sectors; a [k-part][row] image with one row per lane asked for 16 of every 64 bytes, 64 requests per instruction).
+    //         The image is [row][k-part] in 16-byte slots with the k-part XOR-ed by (row >> 2) & 3, so that the 16 lanes of a
+    //         ds_read_b128 group (16 rows, one k-part) hit 16 different slots modulo 16.
+    // Partial tiles read clamped rows / columns (pad, don't mask).
     const int drow = lane >> 4, dslot = lane & 15;
     int64_t dcol = bcol0 + 8 * ((((dslot >> 2) ^ drow) << 2) | (dslot & 3));
     if (dcol > key.cols - 8) dcol = key.cols - 8;
-    const uint32_t d_lane = (uint32_t)(((int64_t)drow * key.cols + dcol) * 2);
-    uint32_t urow;
-    { const int64_t rr = brow0 + 64 * (wave & 1) + lane; urow = (uint32_t)(rr < last_row ? rr : last_row); }
+    const uint32_t d_lane0 = (uint32_t)(((int64_t)(8 * wave + drow) * key.cols + dcol) * 2);
+    const uint32_t d_step = (uint32_t)(key.cols * 8);                                       // 4 rows further
+    uint32_t urow[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) { const int64_t rr = brow0 + 16 * (2 * wave + j) + (lane >> 2); urow[j] = (uint32_t)(rr < last_row ? rr : last_row); }
+    const uint32_t u_part = 16u * (uint32_t)((lane & 3) ^ ((lane >> 4) & 3));               // (row >> 2) & 3 of row 16 m + (lane >> 2)
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte *)ring) + (uint32_t)wave * 2048u;
 
     // ---- LDS read offsets of this lane (bytes inside a stage)
     const int q = (lane & 15) >> 2, pp = lane & 3, gbit = (lane >> 4) & 1;
-    const int a_lane = (8 * h + q) * 256 + ((16 * gbit + 4 * pp) << 1);                     // + (16 s + 4 f) * 256 + window
-    const int a_win = (((wcol >> 5) ^ q) << 6);
-    const int b_lane = STAGE_UP + (h * 128 + wrow + r) * 16;                                // + (2 s * 128 + 32 rg) * 16
-
-    // ---- the chunk sequence over (network, k0)
-    struct Chunk { int n, k0; bool ok; };
-    int n = 0, k0 = 0;
-    const int n_nets = key.net_count;
-    auto take = [&]() {
-        Chunk c{n, k0, n < n_nets};
-        if (c.ok) { k0 += KC; if (k0 >= nets[n].rank) { k0 = 0; n++; } }
-        return c;
-    };
-    int cur_rank = 0;
-    uint32_t u_lane = 0u;
-    auto issue = [&](const Chunk &c, int slot) {
-        const mecha_lora_net net = nets[c.n];
-        if (net.rank != cur_rank) {
-            cur_rank = net.rank;
-            u_lane = urow * (uint32_t)net.rank * 2u;
-        }
-        unsigned char *stage = ring + slot * STAGE_BYTES + wave * 1024;
-        const char *dn = static_cast<const char *>(net.down) + (int64_t)(c.k0 + 4 * wave) * key.cols * 2;
-        glds16(dn + d_lane, stage);
-        const char *upb = static_cast<const char *>(net.up) + c.k0 * 2 + (wave >> 1) * 16;
-        glds16(upb + u_lane, stage + STAGE_UP);
-    };
-
-    // prologue: RING - 1 stages in flight, then the base tile
-    Chunk pending[RING];                                                  // pending[i]: the chunk held by slot i
-    int issued = 0;
+    const int a_lane = (8 * h + q) * 256 + 32 * (pp & 1) + 16 * gbit + 8 * (pp >> 1);       // + 16 s * 256 + window
+    int a_win[2];
 #pragma unroll
-    for (int i = 0; i < RING - 1; i++) {
-        pending[i] = take();
-        if (pending[i].ok) { issue(pending[i], i); issued++; }
-    }
-    pending[RING - 1] = Chunk{0, 0, false};
+    for (int cg = 0; cg < 2; cg++) a_win[cg] = ((((wcol >> 5) + cg) ^ q) << 6);
+    int b_lane[2];                                                                          // + 32 rg * 64
+#pragma unroll
+    for (int s = 0; s < 2; s++) b_lane[s] = STAGE_UP + (4 * (wrow + r) + ((2 * s + h) ^ ((r >> 2) & 3))) * 16;
 
-    // ---- the base tile: every load is issued before the first one is consumed, no branch between them.  Rows / columns
-    // past the key's edge read clamped addresses (the key's last row, its last 4 columns) and are zeroed afterwards.
-    f32x16 total[2];
-    f32x2 poison_in = {0.0f, 0.0f};
-    const f32x2 zero2 = {0.0f, 0.0f};
-    bool in_row[2], in_col[4];
-    int64_t at[2][4];
+    // ---- the ring
+    uint32_t pflags[RING];
+    float pscale[RING], pweight[RING];
+    int next = 0;                                                         // chunks issued so far
+    auto issue = [&](int slot) {
+        const LoraChunk c = chunks[next];
+        next++;
+        pflags[slot] = c.flags; pscale[slot] = c.scale; pweight[slot] = c.weight;
+        const char *d0 = c.down + d_lane0;
+        const char *u0 = c.up + (urow[0] * c.rank2 + u_part);
+        const char *u1 = c.up + (urow[1] * c.rank2 + u_part);
+        const uint32_t stage = ring_lds + (uint32_t)slot * STAGE_BYTES;
+        glds16x4(d0, d0 + d_step, u0, u1, stage, stage + STAGE_UP);
+    };
+    // prologue: RING - 1 stages in flight, then the base tile's loads (consumed at the first fold: they have the rounds
+    // before it to arrive; the counted waits below leave them in flight)
+#pragma unroll
+    for (int i = 0; i < RING - 1; i++)
+        if (next < n_chunks) issue(i);
+    const int issued0 = next;                                             // stages older than the base loads
+
+    // ---- the base tile.  total[rg][cg] first holds the raw words (16-bit base: 8 dwords, f32: 16), then the fp32 values.
+    // Rows / columns past the key's edge read clamped addresses and are zeroed when the words are unpacked.
+    f32x16 total[2][2];
+    bool in_row[2], in_col[2][2];
+    int64_t row_at[2];                                                    // element index of this lane's rows, and its 8-column pieces inside a row
+    int col_at[2][2];
 #pragma unroll
     for (int rg = 0; rg < 2; rg++) {
-        const int64_t row = row0 + 32 * rg;
+        const int64_t row = brow0 + wrow + 32 * rg + r;
         in_row[rg] = row < key.rows;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int64_t c = bcol0 + wcol + 8 * g + 4 * h;
-            in_col[g] = c < key.cols;                                     // cols % 8 == 0: a group of 4 is inside or outside as a whole
-            at[rg][g] = key.offset + (in_row[rg] ? row : last_row) * key.cols + (in_col[g] ? c : key.cols - 4);
-        }
+        row_at[rg] = key.offset + (in_row[rg] ? row : last_row) * key.cols;
     }
-    auto load_base = [&](auto dt_tag) {
-        constexpr int BDT = decltype(dt_tag)::value;
-        typedef typename std::conditional<BDT == MECHA_F32, f32x4, u16x4>::type raw_t;
-        raw_t raw[2][4];
 #pragma unroll
-        for (int rg = 0; rg < 2; rg++)
+    for (int cg = 0; cg < 2; cg++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) raw[rg][g] = *reinterpret_cast<const raw_t *>(base + at[rg][g] * (BDT == MECHA_F32 ? 4 : 2));
-#pragma unroll
-        for (int rg = 0; rg < 2; rg++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float v[4];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    float x;
-                    if constexpr (BDT == MECHA_F32) x = raw[rg][g][q4];
-                    else if constexpr (BDT == MECHA_BF16) x = bf16_bits_to_f32(raw[rg][g][q4]);
-                    else x = f16_bits_to_f32(raw[rg][g][q4]);
-                    v[q4] = (in_row[rg] && in_col[g]) ? x : 0.0f;
-                }
-                poison_in = __builtin_elementwise_fma(f32x2{v[0], v[1]}, zero2, poison_in);
-                poison_in = __builtin_elementwise_fma(f32x2{v[2], v[3]}, zero2, poison_in);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) total[rg][g * 4 + q4] = v[q4];
-            }
-    };
+        for (int j = 0; j < 2; j++) {
+            const int64_t c = bcol0 + wcol + 32 * cg + 16 * h + 8 * j;
+            in_col[cg][j] = c < key.cols;                                 // cols % 8 == 0: a piece is inside or outside as a whole
+            col_at[cg][j] = (int)(in_col[cg][j] ? c : key.cols - 8);
+        }
+    const int base_loads = base == nullptr ? 0 : (p.base_dt == MECHA_F32 ? 16 : 8);
+    bool unpacked = base == nullptr;
     if (base == nullptr) {
 #pragma unroll
         for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) total[rg][i] = 0.0f;
-    } else if (p.base_dt == MECHA_BF16) load_base(std::integral_constant<int, MECHA_BF16>{});
-    else if (p.base_dt == MECHA_F16) load_base(std::integral_constant<int, MECHA_F16>{});
-    else load_base(std::integral_constant<int, MECHA_F32>{});
+            for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) total[rg][cg][i] = 0.0f;
+    } else if (p.base_dt == MECHA_F32) {
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(base + ((row_at[rg] + col_at[cg][j]) + 4 * v) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) total[rg][cg][8 * j + 4 * v + e] = w[e];
+                    }
+    } else {
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(base + (row_at[rg] + col_at[cg][j]) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) total[rg][cg][4 * j + e] = w[e];
+                }
+    }
+    f32x2 poison_in = {0.0f, 0.0f};
+    const f32x2 zero2 = {0.0f, 0.0f};
+    auto unpack_base = [&]() {                                            // raw words -> fp32 values, in place
+        unpacked = true;
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int cg = 0; cg < 2; cg++) {
+                float v[16];
+                if (p.base_dt == MECHA_F32) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = total[rg][cg][i];
+                } else {
+                    uint32_t w[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) w[i] = __float_as_uint(total[rg][cg][i]);
+                    if (p.base_dt == MECHA_BF16) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) { v[2 * i] = f16_bits_to_f32(w[i] & 0xffffu); v[2 * i + 1] = f16_bits_to_f32(w[i] >> 16); }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = (in_row[rg] && in_col[cg][i >> 3]) ? v[i] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) poison_in = __builtin_elementwise_fma(f32x2{v[i], v[i + 1]}, zero2, poison_in);
+#pragma unroll
+                for (int i = 0; i < 16; i++) total[rg][cg][i] = v[i];
+            }
+    };
 
     u16x8v mag = {0, 0, 0, 0, 0, 0, 0, 0};                                                  // running max of |factor| bit patterns (edge tiles)
     const u16x8v abs_mask = {0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff};
-    f32x16 acc[2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[rg][i] = 0.0f;
+        for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[rg][cg][i] = 0.0f;
 
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     int done = 0;                                                         // chunks consumed so far
     // one round: wait for the stage in `slot`, refill the slot read in the previous round, multiply
     auto round = [&](int slot) {
-        const Chunk now = pending[slot];
-        const int later = issued - done - 1;                              // stages issued after this one: 0 .. RING - 2
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // vmcnt retires in order: allow the stages issued after this one and, while this stage is older than they are, the base loads
+        wait_vm(DMA_PER_STAGE * (next - done - 1) + (done < issued0 ? base_loads : 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        {
-            const int refill = (slot + RING - 1) % RING;
-            pending[refill] = take();
-            if (pending[refill].ok) { issue(pending[refill], refill); issued++; }
-        }
+        const uint32_t flags = pflags[slot];
+        const float scale = pscale[slot], weight = pweight[slot];
+        if (next < n_chunks) issue((slot + RING - 1) % RING);
         const unsigned char *stage = ring + slot * STAGE_BYTES;
-        u16x8 a[2], b[2][2];                                              // [k-step], [k-step][row group]
+        u16x8 a[2][2], b[2][2];                                           // [k-step][column group], [k-step][row group]
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            {
-                const unsigned char *at = stage + a_lane + a_win + 16 * s * 256;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(at + 4 * 256));
-                a[s] = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int cg = 0; cg < 2; cg++) {
+                const unsigned char *src = stage + a_lane + a_win[cg] + 16 * s * 256;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(src));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(src + 4 * 256));
+                a[s][cg] = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
-            for (int rg = 0; rg < 2; rg++) b[s][rg] = *reinterpret_cast<const u16x8 *>(stage + b_lane + (2 * s * 128 + 32 * rg) * 16);
+            for (int rg = 0; rg < 2; rg++) b[s][rg] = *reinterpret_cast<const u16x8 *>(stage + b_lane[s] + 32 * rg * 64);
         }
-        const mecha_lora_net net = nets[now.n];
-        // Consecutive networks with the same (scale, weight) share ONE accumulator chain and one fold (NET_* bits, set when
-        // the key is entered): sum_i fma(delta_i * s, w, .) and fma((sum_i delta_i) * s, w, .) differ by fp32 rounding of the
-        // partial sums only, inside the parity bar of this method (BLAS-ordered sgemm in the reference: <= 1 ulp of the output
-        // dtype).  A fold per rank-32 network cost as many instructions as its four MFMAs.
-        // The chain always accumulates; the accumulators are cleared where a group ends (below) and at the start of the tile.
-        // (Starting a group with C = 0 as an inline constant in one branch and accumulating in the other made the compiler
-        // keep two register sets for the accumulators: 16 v_mov_b64 behind an s_nop 10 in EVERY round, between the MFMA pairs.)
+        // Consecutive networks with the same (scale, weight) share ONE accumulator chain and one fold (CH_FOLD closes the run):
+        // sum_i fma(delta_i * s, w, .) and fma((sum_i delta_i) * s, w, .) differ by fp32 rounding of the partial sums only, inside
+        // the parity bar of this method (BLAS-ordered sgemm in the reference: <= 1 ulp of the output dtype).  The chain always
+        // accumulates; the accumulators are cleared where a run ends and at the start of the tile (C = 0 as an inline constant
+        // in one branch made the compiler keep two accumulator register sets).
 #pragma unroll
-        for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[0], b[0][rg], acc[rg]);
+        for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int rg = 0; rg < 2; rg++) acc[rg] = mfma16<LDT>(a[1], b[1][rg], acc[rg]);
-        if (check_down)                                                   // this thread's 16 bytes of the down slab
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) acc[rg][cg] = mfma16<LDT>(a[s][cg], b[s][rg], acc[rg][cg]);
+        if (check_down) {                                                 // this thread's 32 bytes of the down slab
             mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + t * 16) & abs_mask);
-        if (check_up)
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + 4096 + t * 16) & abs_mask);
+        }
+        if (check_up) {
             mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + t * 16) & abs_mask);
-        if (now.k0 + KC >= net.rank && (net.reserved & NET_ENDS_GROUP)) { // the group is complete: delta * scale, then addcmul
-            const float scale = net.scale, weight = net.weight;
+            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + 4096 + t * 16) & abs_mask);
+        }
+        if (flags & CH_FOLD) {                                            // the run is complete: delta * scale, then addcmul
+            if (!unpacked) unpack_base();
             // fma(round(acc * scale), weight, total) (lycoris.py:263 then linear.py:76).  With a power-of-two scale (alpha / rank
             // usually is one) acc * scale and scale * weight are exact, so one fma gives the same bits; two per instruction
             // (v_pk_fma_f32).  Only results below the normal range could differ, where acc * scale would round and this does not.
-            if (net.reserved & NET_ONE_STEP) {
+            if (flags & CH_ONE_STEP) {
                 const f32x2 sw = {scale * weight, scale * weight};
 #pragma unroll
                 for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const f32x2 f = __builtin_elementwise_fma(f32x2{acc[rg][i], acc[rg][i + 1]}, sw, f32x2{total[rg][i], total[rg][i + 1]});
-                        total[rg][i] = f.x; total[rg][i + 1] = f.y;
-                    }
+                    for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) {
+                            const f32x2 f = __builtin_elementwise_fma(f32x2{acc[rg][cg][i], acc[rg][cg][i + 1]}, sw, f32x2{total[rg][cg][i], total[rg][cg][i + 1]});
+                            total[rg][cg][i] = f.x; total[rg][cg][i + 1] = f.y;
+                        }
             } else {
 #pragma unroll
                 for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-                    for (int i = 0; i < 16; i++) total[rg][i] = __builtin_fmaf(acc[rg][i] * scale, weight, total[rg][i]);
+                    for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) total[rg][cg][i] = __builtin_fmaf(acc[rg][cg][i] * scale, weight, total[rg][cg][i]);
             }
 #pragma unroll
             for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) acc[rg][i] = 0.0f;
+                for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc[rg][cg][i] = 0.0f;
         }
         done++;
     };
     while (true) {
-        if (!pending[0].ok) break;
+        if (done >= n_chunks) break;
         round(0);
-        if (!pending[1].ok) break;
+        if (done >= n_chunks) break;
         round(1);
-        if (!pending[2].ok) break;
+        if (done >= n_chunks) break;
         round(2);
-        if (!pending[3].ok) break;
+        if (done >= n_chunks) break;
         round(3);
     }
+    if (!unpacked) unpack_base();                                         // a key without networks: out = base
 
     f32x2 poison_out = {0.0f, 0.0f};
     char *outp = static_cast<char *>(p.out);
@@ -422,20 +497,28 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
 #pragma unroll
         for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                if (in_row[rg] && in_col[g]) {
-                    float v[4];
+            for (int cg = 0; cg < 2; cg++) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) v[q4] = total[rg][g * 4 + q4];
-                    poison_out = __builtin_elementwise_fma(f32x2{v[0], v[1]}, zero2, poison_out);
-                    poison_out = __builtin_elementwise_fma(f32x2{v[2], v[3]}, zero2, poison_out);
-                    if constexpr (ODT == MECHA_F32) {
-                        *reinterpret_cast<f32x4 *>(outp + at[rg][g] * 4) = f32x4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        u16x4 w;
+                for (int i = 0; i < 16; i += 2) poison_out = __builtin_elementwise_fma(f32x2{total[rg][cg][i], total[rg][cg][i + 1]}, zero2, poison_out);
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; q4++) w[q4] = (uint16_t)(ODT == MECHA_BF16 ? f32_to_bf16_bits(v[q4]) : f32_to_f16_bits(v[q4]));
-                        *reinterpret_cast<u16x4 *>(outp + at[rg][g] * 2) = w;
+                for (int j = 0; j < 2; j++) {
+                    if (in_row[rg] && in_col[cg][j]) {
+                        if constexpr (ODT == MECHA_F32) {
+#pragma unroll
+                            for (int v = 0; v < 2; v++) {
+                                const int i0 = 8 * j + 4 * v;
+                                *reinterpret_cast<f32x4 *>(outp + ((row_at[rg] + col_at[cg][j]) + 4 * v) * 4) =
+                                    f32x4{total[rg][cg][i0], total[rg][cg][i0 + 1], total[rg][cg][i0 + 2], total[rg][cg][i0 + 3]};
+                            }
+                        } else {
+                            u32x4 w;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float lo = total[rg][cg][8 * j + 2 * e], hi = total[rg][cg][8 * j + 2 * e + 1];
+                                w[e] = ODT == MECHA_BF16 ? (f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16)) : (f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16));
+                            }
+                            *reinterpret_cast<u32x4 *>(outp + (row_at[rg] + col_at[cg][j]) * 2) = w;
+                        }
                     }
                 }
             }
@@ -620,13 +703,15 @@ __device__ __forceinline__ void lora_tile_general(const LoraParams &p, const mec
 // 14.9 ms for the SDXL x16 batch).  A block walks the key table forward with a parallel search.  On a key change the key's network table goes to LDS with one parallel load
 // (every later access is an LDS read: a global load inside the k-loop would have to wait out the LDS-DMA ring, vmcnt is
 // in order) and the same threads evaluate the fast / general test.
-constexpr int LORA_FAST_BLOCK = 512;            // the fast kernel: 8 waves, wave tile 32 columns x 64 rows
-// (two blocks per CU -- __launch_bounds__(512, 4): 128 VGPRs, 26 of them spilled, 2 x 65 KB of LDS -- took 13.6 ms for the SDXL x16
-//  batch against 11.5 ms with one block per CU: round 2)
+constexpr int LORA_FAST_BLOCK = 256;            // the fast kernel: 4 waves, wave tile 64 x 64, two blocks per CU
+// (round 2, on the 8-wave / 128 x 128 / one block per CU version: two of those blocks per CU -- __launch_bounds__(512, 4):
+//  128 VGPRs, 26 of them spilled -- took 13.6 ms for the SDXL x16 batch against 11.5 ms)
 template <int LDT, bool BATCHED, bool FAST>
-__global__ __launch_bounds__(FAST ? LORA_FAST_BLOCK : MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd) {
+__global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FAST ? RING * STAGE_BYTES : 2 * SLAB_HALFS * 2];
     __shared__ __attribute__((aligned(16))) mecha_lora_net s_nets[LORA_MAX_NETS];
+    __shared__ LoraChunk s_chunks[FAST ? MAX_CHUNKS : 1];
+    __shared__ int s_chunk_count;
     uint16_t (&lds)[2][SLAB_HALFS] = *reinterpret_cast<uint16_t (*)[2][SLAB_HALFS]>(lds_raw);
     // ---- this block's tiles: x0 + j, x0 + j + nb, ... of its XCD's range (the XCD's resident blocks work on neighbouring
     // tiles at any moment: one key's factors in the L2, not one key per block)
@@ -653,18 +738,16 @@ __global__ __launch_bounds__(FAST ? LORA_FAST_BLOCK : MECHA_BLOCK, 2) void lora_
         if constexpr (BATCHED) key = p.keys[ki]; else key = p.key0;
         const int64_t tiles_x = (key.cols + LORA_TILE - 1) / LORA_TILE, tiles_y = (key.rows + LORA_TILE - 1) / LORA_TILE;
         key_end = key.tile_start + tiles_x * tiles_y;
-        int ok = ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 3) == 0) && key.rows < ((int64_t)1 << 31);
+        int ok = ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 7) == 0) && key.rows < ((int64_t)1 << 31);
+        mecha_lora_net net{};
         if ((int)threadIdx.x < key.net_count) {
-            mecha_lora_net net;
             if constexpr (BATCHED) net = p.nets[key.net_begin + threadIdx.x]; else net = p.net0[threadIdx.x];
             // group bits for the fast path: neighbours with the same (scale, weight) share an accumulator chain
             const int i = threadIdx.x;
-            mecha_lora_net prev = net, next = net;
+            mecha_lora_net next = net;
             if constexpr (BATCHED) {
-                if (i > 0) prev = p.nets[key.net_begin + i - 1];
                 if (i + 1 < key.net_count) next = p.nets[key.net_begin + i + 1];
             } else {
-                if (i > 0) prev = p.net0[i - 1];
                 if (i + 1 < key.net_count) next = p.net0[i + 1];
             }
             auto same = [](const mecha_lora_net &x, const mecha_lora_net &y) {
@@ -672,12 +755,31 @@ __global__ __launch_bounds__(FAST ? LORA_FAST_BLOCK : MECHA_BLOCK, 2) void lora_
             };
             const uint32_t sb = __float_as_uint(net.scale), swb = __float_as_uint(net.scale * net.weight);
             const bool one_step = ((sb & 0x007fffffu) == 0u) && (((sb >> 23) & 0xffu) - 1u < 254u) && (((swb >> 23) & 0xffu) - 1u < 254u);
-            net.reserved = ((i == 0 || !same(prev, net)) ? NET_STARTS_GROUP : 0) | ((i + 1 == key.net_count || !same(next, net)) ? NET_ENDS_GROUP : 0) |
-                           (one_step ? NET_ONE_STEP : 0);
+            net.reserved = ((i + 1 == key.net_count || !same(next, net)) ? NET_ENDS_GROUP : 0) | (one_step ? NET_ONE_STEP : 0);
             s_nets[threadIdx.x] = net;
             ok = ok && ((net.rank & 31) == 0) && (((reinterpret_cast<uintptr_t>(net.up) | reinterpret_cast<uintptr_t>(net.down)) & 15u) == 0) &&
                  (key.rows * (int64_t)net.rank < ((int64_t)1 << 30));
         }
+        __syncthreads();
+        // the key's chunk sequence: thread i writes the chunks of network i behind those of the networks before it
+        if ((int)threadIdx.x < key.net_count) {
+            int64_t first = 0;
+            for (int m = 0; m < (int)threadIdx.x; m++) first += s_nets[m].rank >> 5;
+            const int count = net.rank >> 5;
+            if ((int)threadIdx.x + 1 == key.net_count) s_chunk_count = first + count <= MAX_CHUNKS ? (int)(first + count) : 0;
+            if (first + count > MAX_CHUNKS) ok = 0;
+            else if constexpr (FAST) {
+                for (int c = 0; c < count; c++) {
+                    LoraChunk ch;
+                    ch.down = static_cast<const char *>(net.down) + (int64_t)c * KC * key.cols * 2;
+                    ch.up = static_cast<const char *>(net.up) + c * KC * 2;
+                    ch.rank2 = (uint32_t)net.rank * 2u;
+                    ch.flags = (c + 1 == count && (net.reserved & NET_ENDS_GROUP) ? CH_FOLD : 0u) | ((net.reserved & NET_ONE_STEP) ? CH_ONE_STEP : 0u);
+                    ch.scale = net.scale; ch.weight = net.weight;
+                    s_chunks[first + c] = ch;
+                }
+            }
+        } else if (threadIdx.x == 0) s_chunk_count = 0;                   // a key without networks
         fast = __syncthreads_and(ok) != 0;
     };
     for (int64_t t = x0 + j; t < x1; t += nb) {
@@ -689,7 +791,7 @@ __global__ __launch_bounds__(FAST ? LORA_FAST_BLOCK : MECHA_BLOCK, 2) void lora_
         const int64_t local = t - key.tile_start;
         const int64_t tiles_x = (key.cols + LORA_TILE - 1) / LORA_TILE;
         const int64_t tile_y = local / tiles_x, tile_x = local % tiles_x;
-        if constexpr (FAST) lora_tile_fast<LDT>(p, key, s_nets, key_index, tile_x, tile_y, lds_raw);
+        if constexpr (FAST) lora_tile_fast<LDT>(p, key, s_chunks, s_chunk_count, key_index, tile_x, tile_y, lds_raw);
         else lora_tile_general<LDT>(p, key, s_nets, key_index, tile_x, tile_y, lds);
     }
 }
@@ -700,7 +802,7 @@ bool net_is_fast(const mecha_lora_net &net, int64_t rows) {
            (rows * (int64_t)net.rank < ((int64_t)1 << 30));
 }
 bool key_is_fast(const mecha_lora_key &key) {
-    return ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 3) == 0) && key.rows < ((int64_t)1 << 31);
+    return ((key.cols & 7) == 0) && key.cols >= 8 && key.cols < ((int64_t)1 << 25) && ((key.offset & 7) == 0) && key.rows < ((int64_t)1 << 31);
 }
 
 // blocks of `kernel` that fit one CU at once (asked once per kernel and device)
@@ -767,7 +869,9 @@ int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t col
     const int64_t tiles = ((cols + LORA_TILE - 1) / LORA_TILE) * ((rows + LORA_TILE - 1) / LORA_TILE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool fast = key_is_fast(p.key0);
-    for (int i = 0; i < n && fast; i++) fast = net_is_fast(p.net0[i], rows);
+    int64_t chunks = 0;
+    for (int i = 0; i < n && fast; i++) { fast = net_is_fast(p.net0[i], rows); chunks += p.net0[i].rank >> 5; }
+    fast = fast && chunks <= MAX_CHUNKS;
     return lora_dtype == MECHA_F16 ? launch_lora<MECHA_F16, false>(p, tiles, fast, !fast, s) : launch_lora<MECHA_BF16, false>(p, tiles, fast, !fast, s);
 }
 
@@ -784,7 +888,12 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
         const mecha_lora_key &k = keys_host[i];
         if (nets_host != nullptr) {
             bool fast = key_is_fast(k);
-            for (int j = 0; j < k.net_count && fast && k.net_begin >= 0; j++) fast = net_is_fast(nets_host[k.net_begin + j], k.rows);
+            int64_t chunks = 0;
+            for (int j = 0; j < k.net_count && fast && k.net_begin >= 0; j++) {
+                fast = net_is_fast(nets_host[k.net_begin + j], k.rows);
+                chunks += nets_host[k.net_begin + j].rank >> 5;
+            }
+            fast = fast && chunks <= MAX_CHUNKS;
             any_fast |= fast; any_general |= !fast;
         }
         MECHA_REQUIRE(k.rows >= 1 && k.cols >= 1 && k.offset >= 0 && k.net_begin >= 0 && k.net_count >= 0 && k.net_count <= LORA_MAX_NETS,
