@@ -28,6 +28,7 @@
 // per checkpoint; a launch per key costs more than its tiles).  Workgroups go round-robin over the 8 XCDs, each with its
 // own L2: block b takes tile (b % 8) * ceil(T / 8) + b / 8, so that one XCD works through a contiguous run of tiles and a
 // key's factors are fetched into one L2, not eight.
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -222,17 +223,21 @@ __device__ __forceinline__ void glds16x4(const char *s0, const char *s1, const c
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "s"(down_lds), "s"(d1), "s"(up_lds), "s"(u1) : "memory");
 }
-// s_waitcnt vmcnt(n) for the counts the rounds use (multiples of 4 up to 24)
+// running max over the magnitudes of 16-bit floats, two per word: v_and_b32 + v_pk_max_u16 per word, one accumulator
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_abs16(uint32_t m, u32x4 w) {
+    const uint32_t k = 0x7fff7fffu;
+    return pk_max_u16(pk_max_u16(m, pk_max_u16(w[0] & k, w[1] & k)), pk_max_u16(w[2] & k, w[3] & k));
+}
+// s_waitcnt vmcnt(n) for the counts the rounds use
 __device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    }
+    if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   // the steady state: two later stages in flight
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Block = 4 waves, block tile 128 x 128, wave tile 64 columns x 64 rows (2 x 2 MFMA tiles: 8 MFMAs per round and wave for
@@ -297,12 +302,10 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
         const uint32_t stage = ring_lds + (uint32_t)slot * STAGE_BYTES;
         glds16x4(d0, d0 + d_step, u0, u1, stage, stage + STAGE_UP);
     };
-    // prologue: RING - 1 stages in flight, then the base tile's loads (consumed at the first fold: they have the rounds
-    // before it to arrive; the counted waits below leave them in flight)
+    // prologue: RING - 1 stages in flight, then the base tile
 #pragma unroll
     for (int i = 0; i < RING - 1; i++)
         if (next < n_chunks) issue(i);
-    const int issued0 = next;                                             // stages older than the base loads
 
     // ---- the base tile.  total[rg][cg] first holds the raw words (16-bit base: 8 dwords, f32: 16), then the fp32 values.
     // Rows / columns past the key's edge read clamped addresses and are zeroed when the words are unpacked.
@@ -324,8 +327,6 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
             in_col[cg][j] = c < key.cols;                                 // cols % 8 == 0: a piece is inside or outside as a whole
             col_at[cg][j] = (int)(in_col[cg][j] ? c : key.cols - 8);
         }
-    const int base_loads = base == nullptr ? 0 : (p.base_dt == MECHA_F32 ? 16 : 8);
-    bool unpacked = base == nullptr;
     if (base == nullptr) {
 #pragma unroll
         for (int rg = 0; rg < 2; rg++)
@@ -361,7 +362,6 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     f32x2 poison_in = {0.0f, 0.0f};
     const f32x2 zero2 = {0.0f, 0.0f};
     auto unpack_base = [&]() {                                            // raw words -> fp32 values, in place
-        unpacked = true;
 #pragma unroll
         for (int rg = 0; rg < 2; rg++)
 #pragma unroll
@@ -391,8 +391,11 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
             }
     };
 
-    u16x8v mag = {0, 0, 0, 0, 0, 0, 0, 0};                                                  // running max of |factor| bit patterns (edge tiles)
-    const u16x8v abs_mask = {0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff, 0x7fff};
+    // Consumed here, not at the first fold: loads the compiler knows about, pending across the rounds, make it put its own
+    // s_waitcnt vmcnt in front of whatever touches their registers -- in the unrolled ring that was a full drain every fourth
+    // round.  The wait below costs one HBM latency per tile, beside the first stages' landing; the CU's other block computes.
+    if (base != nullptr) unpack_base();
+    uint32_t mag = 0u;                                                                      // running max of |factor| bit patterns, two per word (edge tiles)
     f32x16 acc[2][2];
 #pragma unroll
     for (int rg = 0; rg < 2; rg++)
@@ -405,8 +408,8 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     int done = 0;                                                         // chunks consumed so far
     // one round: wait for the stage in `slot`, refill the slot read in the previous round, multiply
     auto round = [&](int slot) {
-        // vmcnt retires in order: allow the stages issued after this one and, while this stage is older than they are, the base loads
-        wait_vm(DMA_PER_STAGE * (next - done - 1) + (done < issued0 ? base_loads : 0));
+        // vmcnt retires in order: allow the stages issued after this one
+        wait_vm(DMA_PER_STAGE * (next - done - 1));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const uint32_t flags = pflags[slot];
@@ -426,6 +429,7 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
 #pragma unroll
             for (int rg = 0; rg < 2; rg++) b[s][rg] = *reinterpret_cast<const u16x8 *>(stage + b_lane[s] + 32 * rg * 64);
         }
+        __builtin_amdgcn_sched_barrier(0);                                // all twelve reads in flight before the first MFMA waits
         // Consecutive networks with the same (scale, weight) share ONE accumulator chain and one fold (CH_FOLD closes the run):
         // sum_i fma(delta_i * s, w, .) and fma((sum_i delta_i) * s, w, .) differ by fp32 rounding of the partial sums only, inside
         // the parity bar of this method (BLAS-ordered sgemm in the reference: <= 1 ulp of the output dtype).  The chain always
@@ -438,15 +442,14 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
 #pragma unroll
                 for (int cg = 0; cg < 2; cg++) acc[rg][cg] = mfma16<LDT>(a[s][cg], b[s][rg], acc[rg][cg]);
         if (check_down) {                                                 // this thread's 32 bytes of the down slab
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + t * 16) & abs_mask);
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + 4096 + t * 16) & abs_mask);
+            mag = pk_max_abs16(mag, *reinterpret_cast<const u32x4 *>(stage + t * 16));
+            mag = pk_max_abs16(mag, *reinterpret_cast<const u32x4 *>(stage + 4096 + t * 16));
         }
         if (check_up) {
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + t * 16) & abs_mask);
-            mag = __builtin_elementwise_max(mag, *reinterpret_cast<const u16x8v *>(stage + STAGE_UP + 4096 + t * 16) & abs_mask);
+            mag = pk_max_abs16(mag, *reinterpret_cast<const u32x4 *>(stage + STAGE_UP + t * 16));
+            mag = pk_max_abs16(mag, *reinterpret_cast<const u32x4 *>(stage + STAGE_UP + 4096 + t * 16));
         }
         if (flags & CH_FOLD) {                                            // the run is complete: delta * scale, then addcmul
-            if (!unpacked) unpack_base();
             // fma(round(acc * scale), weight, total) (lycoris.py:263 then linear.py:76).  With a power-of-two scale (alpha / rank
             // usually is one) acc * scale and scale * weight are exact, so one fma gives the same bits; two per instruction
             // (v_pk_fma_f32).  Only results below the normal range could differ, where acc * scale would round and this does not.
@@ -488,7 +491,6 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
         if (done >= n_chunks) break;
         round(3);
     }
-    if (!unpacked) unpack_base();                                         // a key without networks: out = base
 
     f32x2 poison_out = {0.0f, 0.0f};
     char *outp = static_cast<char *>(p.out);
@@ -528,9 +530,8 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     else store_out(std::integral_constant<int, MECHA_F32>{});
     bool bad_in = (poison_in.x != poison_in.x) || (poison_in.y != poison_in.y);
     const bool bad_out = (poison_out.x != poison_out.x) || (poison_out.y != poison_out.y);
-    const uint16_t inf_bits = LDT == MECHA_F16 ? 0x7c00 : 0x7f80;
-#pragma unroll
-    for (int j = 0; j < 8; j++) bad_in |= mag[j] >= inf_bits;
+    const uint32_t inf_bits = LDT == MECHA_F16 ? 0x7c00u : 0x7f80u;
+    bad_in |= ((mag & 0xffffu) >= inf_bits) | ((mag >> 16) >= inf_bits);
     if ((bad_in | bad_out) && p.flags != nullptr)
         atomicOr(p.flags + key_index, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
 }
@@ -707,7 +708,7 @@ constexpr int LORA_FAST_BLOCK = 256;            // the fast kernel: 4 waves, wav
 // (round 2, on the 8-wave / 128 x 128 / one block per CU version: two of those blocks per CU -- __launch_bounds__(512, 4):
 //  128 VGPRs, 26 of them spilled -- took 13.6 ms for the SDXL x16 batch against 11.5 ms)
 template <int LDT, bool BATCHED, bool FAST>
-__global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd) {
+__global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int64_t n_tiles, int64_t tiles_per_xcd, int run) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FAST ? RING * STAGE_BYTES : 2 * SLAB_HALFS * 2];
     __shared__ __attribute__((aligned(16))) mecha_lora_net s_nets[LORA_MAX_NETS];
     __shared__ LoraChunk s_chunks[FAST ? MAX_CHUNKS : 1];
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int6
     // tiles at any moment: one key's factors in the L2, not one key per block)
     const int64_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = gridDim.x >> 3;
     const int64_t x0 = xcd * tiles_per_xcd, x1 = (x0 + tiles_per_xcd < n_tiles) ? x0 + tiles_per_xcd : n_tiles;
-    if (x0 + j >= x1) return;                                            // whole block
+    if (x0 + j * run >= x1) return;                                      // whole block
     mecha_lora_key key;
     int key_index = 0;
     int64_t key_end = 0;                                                  // first tile after the key
@@ -782,7 +783,11 @@ __global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int6
         } else if (threadIdx.x == 0) s_chunk_count = 0;                   // a key without networks
         fast = __syncthreads_and(ok) != 0;
     };
-    for (int64_t t = x0 + j; t < x1; t += nb) {
+    // `run` consecutive tiles per block and turn: fewer key changes per block (a change is a chain of dependent loads and two
+    // barriers), at the price of run x as many tiles -- and keys' factors -- in flight per XCD.  SDXL x16 rank-32 batch / one
+    // network per key: run 1 9.41 / 4.28 ms, 2 9.23 / 4.13 (the default; MECHA_LORA_RUN), 4 9.65 / 4.02, 8 9.93 / 4.00
+    for (int64_t t0 = x0 + j * run; t0 < x1; t0 += nb * run)
+    for (int64_t t = t0; t < t0 + run && t < x1; t++) {
         __syncthreads();                                                  // the previous tile's readers of the LDS stages and of s_nets are done
         if (t >= key_end) {
             if constexpr (BATCHED) enter_key(seek_key(key_index, t)); else enter_key(0);
@@ -822,13 +827,14 @@ int launch_lora(const LoraParams &p, int64_t tiles, bool any_fast, bool any_gene
     MECHA_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     static const int occ_fast = resident_blocks_per_cu(lora_kernel<LDT, BATCHED, true>, LORA_FAST_BLOCK);
     static const int occ_general = resident_blocks_per_cu(lora_kernel<LDT, BATCHED, false>, MECHA_BLOCK);
+    static const int run = []() { const char *e = getenv("MECHA_LORA_RUN"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 64 ? v : 2; }();
     auto grid_for = [&](int occ) {
         int64_t per_xcd_blocks = ((int64_t)cus * occ + 7) / 8;
         if (per_xcd_blocks > per_xcd) per_xcd_blocks = per_xcd;
         return dim3((unsigned)(per_xcd_blocks * 8));
     };
-    if (any_fast) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, true>), grid_for(occ_fast), dim3(LORA_FAST_BLOCK), 0, s, p, tiles, per_xcd);
-    if (any_general) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, false>), grid_for(occ_general), dim3(MECHA_BLOCK), 0, s, p, tiles, per_xcd);
+    if (any_fast) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, true>), grid_for(occ_fast), dim3(LORA_FAST_BLOCK), 0, s, p, tiles, per_xcd, run);
+    if (any_general) MECHA_LAUNCH(MK_LORA, (lora_kernel<LDT, BATCHED, false>), grid_for(occ_general), dim3(MECHA_BLOCK), 0, s, p, tiles, per_xcd, 1);
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;
 }
