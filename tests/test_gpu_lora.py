@@ -166,3 +166,21 @@ def test_lora_fast_kernel_edges(oracle, ldt):
             bad[0][0 if which == "up" else 1] = tgt
             with pytest.raises(amd.NonFiniteStateDictKeyError):
                 amd.lora_merge(tbase, [tuple(nw) for nw in bad], out_dtype=TDT[bdt], key="k")
+
+
+def test_lora_more_chunks_than_the_fast_table_holds():
+    """The fast kernel keeps a key's k-chunk sequence in a table of 128 entries (csrc/lora.hip MAX_CHUNKS): a key whose networks
+    add up to more 32-deep chunks takes the general kernel, one chunk fewer the fast one; both against fp64 on the host."""
+    import sd_mecha_amd as amd
+    g = torch.Generator().manual_seed(11)
+    rows, cols = 160, 136
+    base = (torch.randn(rows, cols, generator=g) * 0.02).to(torch.bfloat16)
+    for ranks in ([2048, 2048, 32], [2048, 2016, 32]):                   # 129 chunks, 128 chunks
+        nets, want = [], base.double()
+        for r in ranks:
+            up = (torch.randn(rows, r, generator=g) * 0.05).half()
+            down = (torch.randn(r, cols, generator=g) * 0.05).half()
+            nets.append((up.cuda(), down.cuda(), float(r) / 4, 0.5))
+            want = want + (up.double() @ down.double()) * 0.25 * 0.5
+        got = amd.lora_merge(base.cuda(), nets, out_dtype=torch.float32).cpu().double()
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (ranks, (got - want).abs().max())

@@ -227,3 +227,74 @@ def test_batched_rotate_ill_conditioned_wide_keys(oracle, tmp_path, monkeypatch,
         want = oracle.rotate(ta[k], tb[k], alignment=1.0, alpha=0.0, centralization=0.0)
         rel = rotate_rel_error(oracle, ta[k], tb[k], res[k].cpu().numpy(), want, 0.0)
         assert rel <= 1e-3, (k, rel)
+
+
+def test_full_config4_job_properties_and_sampled_keys(oracle):
+    """BASELINE config 4 at FULL size: rotate(A, B, alignment=1, alpha=0) over every key of two SDXL-shaped bf16 checkpoints
+    through merge() (files on tmpfs -> batched plan -> one fp32 file), checked where no CPU SVD of the whole job is affordable:
+    * every strictly tall key (n > p: the full-rank path, svd.py:168-169) by what DEFINES its answer.  With centred
+      A_c, B_c and O_c = out - mean(B): the rows of O_c have the norms of the rows of A_c (the transform is orthogonal), and
+      O_c^T B_c is symmetric positive semidefinite (T = U V^T of A_c^T B_c = U S V^T gives T^T A_c^T B_c = V S V^T; among
+      orthogonal T only the Procrustes solution makes that product symmetric PSD);
+    * 1-d keys: the lerp at alpha = 0, bit for bit;
+    * a spread of keys of every kind (square, wide, conv, tall) against the oracle with the reference's free terms split off."""
+    import pathlib
+    import shutil
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tools"))
+    import bench_e2e
+    import sd_mecha_amd as amd
+    from sd_mecha_amd import merging
+    from sd_mecha_amd.shapes import load_manifest
+    from sd_mecha_amd.streaming import InSafetensorsDict
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30 or shutil.disk_usage("/dev/shm").free < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM and of /dev/shm")
+    manifest = [(k, s, d) for k, s, d in load_manifest("sdxl-sgm") if not d.startswith("int")]
+    work = pathlib.Path("/dev/shm/mecha_test_config4")
+    work.mkdir(parents=True, exist_ok=True)
+    try:
+        dev = torch.device("cuda", 0)
+        pa, pb, po = work / "a.safetensors", work / "b.safetensors", work / "out.safetensors"
+        bench_e2e.write_checkpoint(pa, manifest, 100, dev)
+        bench_e2e.write_checkpoint(pb, manifest, 101, dev)
+        amd.merge(amd.rotate(amd.model(str(pa)), amd.model(str(pb)), alignment=1.0, alpha=0.0), output=str(po), output_dtype=torch.float32,
+                  total_buffer_size=8 << 30)
+        assert merging.last_stats["generic_keys"] == 0
+        a, b, o = InSafetensorsDict(pa), InSafetensorsDict(pb), InSafetensorsDict(po)
+        assert set(o.keys()) == {k for k, _, _ in manifest}
+        tall, worst_norm, worst_asym, worst_eig = 0, 0.0, 0.0, 0.0
+        by_kind = {}
+        for k, s, _ in manifest:
+            if len(s) <= 1:
+                assert torch.equal(o[k], a[k].float()), k                 # lerp(a, b, 0) = a (svd.py:46-47 for 1-d keys)
+                continue
+            n, p = oracle.rotate_shape_2d(s)
+            by_kind.setdefault("conv" if len(s) == 4 and s[2] * s[3] != 1 else "tall" if n > p else "square" if n == p else "wide", []).append(k)
+            if n <= p:
+                continue
+            tall += 1
+            a2, b2, o2 = (x[k].to(dev).reshape(n, p).double() for x in (a, b, o))
+            ac, bc, oc = a2 - a2.mean(0), b2 - b2.mean(0), o2 - b2.mean(0)
+            rn = (oc.norm(dim=1) - ac.norm(dim=1)).norm() / ac.norm()
+            m = oc.T @ bc
+            asym = (m - m.T).norm() / m.norm()
+            worst_norm, worst_asym = max(worst_norm, float(rn)), max(worst_asym, float(asym))
+            assert rn <= 1e-5 and asym <= 1e-4, (k, s, float(rn), float(asym))
+            if p <= 640 or tall % 16 == 0:
+                ev = torch.linalg.eigvalsh((m + m.T) / 2)
+                worst_eig = max(worst_eig, float(-ev[0] / ev[-1]))
+                assert ev[0] >= -1e-5 * ev[-1], (k, s, float(ev[0]), float(ev[-1]))
+        assert tall > 100, tall
+        print(f"config 4 full size: {tall} tall keys, worst row-norm defect {worst_norm:.2e}, asymmetry {worst_asym:.2e}, negative eigenvalue {worst_eig:.2e}")
+        for kind, keys in sorted(by_kind.items()):
+            keys = sorted(keys, key=lambda k: int(np.prod(o[k].shape)))
+            for k in {keys[0], keys[len(keys) // 2]}:
+                if int(np.prod(o[k].shape)) > 8_000_000:
+                    continue
+                ta, tb = a[k].float().numpy(), b[k].float().numpy()
+                want = oracle.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=1.0)
+                rel = rotate_rel_error(oracle, ta, tb, o[k].numpy(), want, 1.0)
+                assert rel <= 1e-3, (kind, k, o[k].shape, rel)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
