@@ -184,3 +184,67 @@ def test_lora_more_chunks_than_the_fast_table_holds():
             want = want + (up.double() @ down.double()) * 0.25 * 0.5
         got = amd.lora_merge(base.cuda(), nets, out_dtype=torch.float32).cpu().double()
         assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (ranks, (got - want).abs().max())
+
+
+def test_full_config5_job_every_key_by_linearity():
+    """BASELINE config 5 at FULL size: an sdxl-kohya-shaped bf16 checkpoint + 16 rank-32 fp16 kohya LoRA files through merge()
+    (files on tmpfs -> descriptor tables -> one batched launch per wave -> one fp32 file).  Every key the networks cover is
+    checked by what the method is -- out - base = sum_i w_i (alpha_i / r_i) up_i . down_i (lycoris.py:226-263, linear.py:76) --
+    with the products taken in fp64 on the device; every other key must be the base, bit for bit."""
+    import pathlib
+    import shutil
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tools"))
+    import bench_e2e
+    import sd_mecha_amd as amd
+    from sd_mecha_amd import merging
+    from sd_mecha_amd.lora import lora_key_prefix
+    from sd_mecha_amd.shapes import load_manifest
+    from sd_mecha_amd.streaming import InSafetensorsDict
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30 or shutil.disk_usage("/dev/shm").free < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM and of /dev/shm")
+    manifest = [(k, s, d) for k, s, d in load_manifest("sdxl-kohya") if not d.startswith("int")]
+    work = pathlib.Path("/dev/shm/mecha_test_config5")
+    work.mkdir(parents=True, exist_ok=True)
+    try:
+        dev = torch.device("cuda", 0)
+        pb, po = work / "base.safetensors", work / "out.safetensors"
+        bench_e2e.write_checkpoint(pb, manifest, 100, dev)
+        loras = []
+        for i in range(bench_e2e.N_LORAS):
+            bench_e2e.write_lora(work / f"lora{i}.safetensors", manifest, 500 + i, dev)
+            loras.append(work / f"lora{i}.safetensors")
+        base_m = amd.model(str(pb))
+        recipe = base_m
+        for p in loras:
+            recipe = amd.add_difference(recipe, amd.convert(amd.model(str(p)), base_m), alpha=1.0) | recipe
+        amd.merge(recipe, output=str(po), output_dtype=torch.float32, total_buffer_size=8 << 30)
+        assert merging.last_stats["generic_keys"] <= 3, merging.last_stats
+        base, out = InSafetensorsDict(pb), InSafetensorsDict(po)
+        nets = [InSafetensorsDict(p) for p in loras]
+        assert set(out.keys()) == {k for k, _, _ in manifest}
+        covered, worst = 0, 0.0
+        for k, s, _ in manifest:
+            prefix = lora_key_prefix(k, s)
+            b = base[k].to(dev)
+            o = out[k].to(dev)
+            if prefix is None or f"{prefix}.lora_up.weight" not in nets[0]:
+                assert torch.equal(o, b.float()), k
+                continue
+            covered += 1
+            rows = s[0]
+            want = b.double().reshape(rows, -1)
+            mag = want.abs()
+            for f in nets:
+                up, down = f[f"{prefix}.lora_up.weight"].to(dev).double(), f[f"{prefix}.lora_down.weight"].to(dev).double().reshape(bench_e2e.LORA_RANK, -1)
+                delta = (up @ down) * (16.0 / bench_e2e.LORA_RANK)
+                want = want + delta
+                mag = mag + delta.abs()
+            err = ((o.double().reshape(rows, -1) - want).abs() / mag.clamp_min(1e-30)).max()
+            worst = max(worst, float(err))
+            assert err <= 4e-6, (k, s, float(err))                       # fp32 rounding of 17 terms of the size of `mag`
+        assert covered > 700, covered
+        print(f"config 5 full size: {covered} covered keys, worst |out - want| / (|base| + sum |delta|) = {worst:.2e}")
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
