@@ -573,3 +573,77 @@ def test_full_config2_job_sampled_keys_vs_oracle(amd, oracle):
         want, det = oracle.ties_sum(deltas, k=0.2, details=True)
         assert np.array_equal(host_bits(thr[i]), det["thresholds"].view(np.uint32)), (L.keys[i], "thresholds")
         assert np.array_equal(host_bits(job.out[o:o + n]), oracle.from_f32(oracle.add_difference(b32, want, 1.0), "bfloat16")), (L.keys[i], n, "output")
+
+
+@pytest.mark.parametrize("workload", ["flux_navg", "flux_ties"])
+def test_full_config3_stripe_vs_oracle(amd, oracle, workload):
+    """BASELINE config 3 at one GPU's FULL share -- the keys LPT deals to rank 0 of 8 from the FLUX-dev diffuser (1.49 B
+    elements), 8 bf16 checkpoints -- in ONE batched launch sequence, as bench.py and merge() run it.  n_average: every element
+    within one bf16 ulp of the fp64 mean (plus the fp32 rounding of the running mean where the values cancel), a spread of keys bit for bit against the oracle.  TIES with 7 deltas: every
+    (key, delta) threshold by its rank property, thresholds and outputs of a spread of keys bit for bit against the oracle."""
+    import ctypes
+    import pathlib
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    import bench
+    from sd_mecha_amd import _lib
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip("needs 60 GB of free HBM")
+    job = bench.Job(workload, 0, torch.device("cuda", 0))
+    L, lib = job.layout, job.lib
+    n_keys, nd = len(L.keys), job.n_models - 1
+    order = sorted(range(n_keys), key=lambda i: L.numels[i])
+    picks = sorted(set(order[:4] + order[len(order) // 2 - 2:len(order) // 2 + 2] + [i for i in order if L.numels[i] <= 40_000_000][-2:]))
+    if workload == "flux_navg":
+        job.step()
+        torch.cuda.synchronize()
+        step = 1 << 26
+        for o in range(0, L.total_elems, step):
+            sl = slice(o, min(o + step, L.total_elems))
+            mean = torch.zeros(sl.stop - sl.start, dtype=torch.float64, device="cuda")
+            for a in job.arenas:
+                mean += a[sl].double()
+            mean /= job.n_models
+            got = job.out[sl].double()
+            # one ulp of a bf16 value of that magnitude, at most; where the eight values cancel, the fp32 rounding of the running mean
+            ulp = torch.maximum(mean.abs(), got.abs()) * 2.0 ** -7 + 1e-7
+            covered = torch.zeros(sl.stop - sl.start, dtype=torch.bool, device="cuda")
+            for off, n in zip(L.offsets, L.numels):
+                lo, hi = max(off, sl.start), min(off + n, sl.stop)
+                if lo < hi:
+                    covered[lo - sl.start:hi - sl.start] = True
+            assert bool((((got - mean).abs() <= ulp) | ~covered).all()), o
+        for i in picks:
+            o, n = L.offsets[i], L.numels[i]
+            f32 = [oracle.to_f32(host_bits(a[o:o + n]), "bfloat16") for a in job.arenas]
+            assert np.array_equal(host_bits(job.out[o:o + n]), oracle.from_f32(oracle.n_average(f32), "bfloat16")), (L.keys[i], n)
+        return
+    thr = torch.zeros((n_keys, nd), dtype=torch.float32, device="cuda")
+    job.flags.zero_()
+    st = lib.mecha_batched_add_difference_ties(
+        job.arenas[0].data_ptr(), job.model_ptrs, nd, job.out.data_ptr(), job.segs_dev.data_ptr(), ctypes.addressof(job.segs_host), n_keys,
+        L.total_elems, _lib.BF16, _lib.BF16, 0.2, 1.0, 0, thr.data_ptr(), job.ws.data_ptr(), job.ws.numel(), job.flags.data_ptr(),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(st, "batched ties")
+    torch.cuda.synchronize()
+    assert int(job.flags.abs().sum().item()) == 0
+    base = job.arenas[0]
+    bad = []
+    for i, (o, n) in enumerate(zip(L.offsets, L.numels)):                # ties.py:128-132: #(|d| < t) < kth <= #(|d| <= t)
+        kth = max(int((1 - 0.2) * n), 1)
+        b32 = base[o:o + n].float()
+        for d in range(nd):
+            dm = (job.arenas[1 + d][o:o + n].float() - b32).abs()
+            t = thr[i, d]
+            if not (int((dm < t).sum().item()) < kth <= int((dm <= t).sum().item())):
+                bad.append((L.keys[i], d))
+    assert not bad, bad[:5]
+    for i in picks:
+        o, n = L.offsets[i], L.numels[i]
+        bits = [host_bits(a[o:o + n]) for a in job.arenas]
+        b32 = oracle.to_f32(bits[0], "bfloat16")
+        deltas = [oracle.subtract(oracle.to_f32(x, "bfloat16"), b32) for x in bits[1:]]
+        want, det = oracle.ties_sum(deltas, k=0.2, details=True)
+        assert np.array_equal(host_bits(thr[i]), det["thresholds"].view(np.uint32)), (L.keys[i], "thresholds")
+        assert np.array_equal(host_bits(job.out[o:o + n]), oracle.from_f32(oracle.add_difference(b32, want, 1.0), "bfloat16")), (L.keys[i], n, "output")
