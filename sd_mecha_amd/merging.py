@@ -190,50 +190,71 @@ class _LoraStore:
     def __init__(self, plan: FusedPlan, readers, device: torch.device, host_threads: int):
         self.expr = plan.params["expr"]
         self.files = []
+        self._hosts = []                                         # pinned staging buffers, until their copies are done
         self.tables_by_file: List[dict] = []
+        copy_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+        pin = dict(pin_memory=True) if device.type == "cuda" else {}
+        np_dtypes = {torch.float16: np.float16, torch.float32: np.float32, torch.float64: np.float64}
+        up_s, down_s, alpha_s = lora_mod.UP, lora_mod.DOWN, "." + lora_mod.ALPHA
         for node in plan.params["loras"]:
             reader = readers[id(node)]
-            names = [k for k, m in reader.metadata() if k.endswith(lora_mod.UP) or k.endswith(lora_mod.DOWN) or k.endswith("." + lora_mod.ALPHA)]
-            offs, total = {}, 0
-            for k in names:
-                offs[k] = total
-                total += (reader.meta(k).nbytes() + 15) // 16 * 16
-            pin = dict(pin_memory=True) if device.type == "cuda" else {}
+            # one pass over the header: staging offsets (16-byte aligned) and the scatter list
+            offs, sizes, foffs, metas, total = {}, [], [], {}, 0
+            data_start = reader.data_start
+            for k, m in reader.metadata():
+                if k.endswith(up_s) or k.endswith(down_s) or k.endswith(alpha_s):
+                    nb = m.end - m.start
+                    offs[k] = total
+                    metas[k] = m
+                    sizes.append(nb)
+                    foffs.append(data_start + m.start)
+                    total += (nb + 15) // 16 * 16
             host = torch.empty(max(total, 16), dtype=torch.uint8, **pin)
-            if names:
-                fds = np.full(len(names), reader.fileno(), dtype=np.int32)
-                dst = np.asarray([host.data_ptr() + offs[k] for k in names], dtype=np.uint64)
-                size = np.asarray([reader.meta(k).nbytes() for k in names], dtype=np.uint64)
-                foff = np.asarray([reader.file_offset(k) for k in names], dtype=np.int64)
+            if offs:
+                fds = np.full(len(offs), reader.fileno(), dtype=np.int32)
+                size = np.asarray(sizes, dtype=np.uint64)
+                dst = np.uint64(host.data_ptr()) + np.fromiter(offs.values(), dtype=np.uint64, count=len(offs))
+                foff = np.asarray(foffs, dtype=np.int64)
                 _lib.check(_lib.lib().mecha_host_pread_many(fds.ctypes.data, dst.ctypes.data, size.ctypes.data, foff.ctypes.data,
-                                                            len(names), host_threads), "mecha_host_pread_many")
-            dev_buf = host.to(device) if device.type == "cuda" else host
+                                                            len(offs), host_threads), "mecha_host_pread_many")
+            if copy_stream is not None:                          # the next file's header pass and preads run beside this copy
+                dev_buf = torch.empty(host.numel(), dtype=torch.uint8, device=device)
+                with torch.cuda.stream(copy_stream):
+                    dev_buf.copy_(host, non_blocking=True)
+            else:
+                dev_buf = host
             self.files.append((reader, dev_buf, offs))
+            self._hosts.append(host)
             # per base-key prefix: (device address of up, of down, rank, scale) -- what a network descriptor holds, computed once
             # per file instead of once per (key, network, wave): alpha / rank as fp32 arithmetic (lycoris.py:263)
             base_ptr = dev_buf.data_ptr()
             host_np = host.numpy()
             table = {}
-            for k in names:
-                if not k.endswith(lora_mod.UP):
+            cut = len(up_s) + 1
+            for k, um in metas.items():
+                if not k.endswith(up_s):
                     continue
-                prefix = k[:-len(lora_mod.UP) - 1]
-                down_k, alpha_k, mid_k = f"{prefix}.{lora_mod.DOWN}", f"{prefix}.{lora_mod.ALPHA}", f"{prefix}.{lora_mod.MID}"
-                if down_k not in offs or mid_k in reader:
+                prefix = k[:-cut]
+                down_k = f"{prefix}.{down_s}"
+                dm = metas.get(down_k)
+                if dm is None or f"{prefix}.{lora_mod.MID}" in reader:
                     continue                                     # incomplete pair / Tucker network: the slow path reports it
-                um, dm = reader.meta(k), reader.meta(down_k)
-                rank = int(dm.shape[0])
+                rank = dm.shape[0]
                 scale = 1.0
-                if alpha_k in offs:                              # the scalar sits in the staging buffer already: no tensor per network
-                    am = reader.meta(alpha_k)
-                    raw = host_np[offs[alpha_k]:offs[alpha_k] + am.nbytes()]
+                am = metas.get(prefix + alpha_s)
+                if am is not None:                               # the scalar sits in the staging buffer already: no tensor per network
+                    o = offs[prefix + alpha_s]
+                    raw = host_np[o:o + am.end - am.start]
                     if am.dtype == torch.bfloat16:
                         alpha = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)[0]
                     else:
-                        alpha = np.float32(raw.view({torch.float16: np.float16, torch.float32: np.float32, torch.float64: np.float64}[am.dtype])[0])
+                        alpha = np.float32(raw.view(np_dtypes[am.dtype])[0])
                     scale = float(np.float32(alpha) / np.float32(rank))
-                table[prefix] = (base_ptr + offs[k], base_ptr + offs[down_k], rank, scale, tuple(um.shape), tuple(dm.shape), um.dtype, dm.dtype)
+                table[prefix] = (base_ptr + offs[k], base_ptr + offs[down_k], rank, scale, um.shape, dm.shape, um.dtype, dm.dtype)
             self.tables_by_file.append(table)
+        if copy_stream is not None:
+            copy_stream.synchronize()
+        self._hosts.clear()
 
     def _tensor(self, f: int, name: str) -> torch.Tensor:
         reader, buf, offs = self.files[f]
@@ -814,10 +835,9 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
 
     host_threads = max(1, min(int(os.environ.get("MECHA_HOST_THREADS", "16")), os.cpu_count() or 1))
     writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+    # the LoRA files' factors (pread + H2D + per-file tables) load on a thread of their own beside the staging of the first wave
     lora_store = None
-    if plan.kind == "lora":
-        with _phase("lora_load"):
-            lora_store = _LoraStore(plan, readers, dev, host_threads)
+    lora_future = writer.submit(_LoraStore, plan, readers, dev, host_threads) if plan.kind == "lora" else None
     hostlib = _lib.lib()
 
     def stage(bs, wave: _Wave):
@@ -1042,6 +1062,9 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     if waves:
         with _phase("stage"):
             stage(sets[0], waves[0])
+    if lora_future is not None:
+        with _phase("lora_load"):
+            lora_store = lora_future.result()
     for w, wave in enumerate(waves):
         bs = sets[w % len(sets)]
         with _phase("launch"):
