@@ -36,6 +36,7 @@
 namespace {
 
 constexpr int LORA_MAX_NETS = MECHA_MAX_MODELS;
+constexpr int LORA_MAX_GENERAL = 256;
 constexpr int KC = 32;                 // k-chunk staged per LDS buffer
 constexpr int LORA_TILE = MECHA_LORA_TILE;   // block tile, rows and columns
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -56,6 +57,9 @@ struct LoraParams {
     int n_keys;
     mecha_lora_key key0;
     mecha_lora_net net0[LORA_MAX_NETS];
+    // batched, general kernel: the keys it has to do, when the host knows them and they fit (else n_general = -1: it walks all tiles)
+    int n_general;
+    int32_t general_keys[LORA_MAX_GENERAL];
 };
 
 template <int LDT>
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int6
     // tiles at any moment: one key's factors in the L2, not one key per block)
     const int64_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = gridDim.x >> 3;
     const int64_t x0 = xcd * tiles_per_xcd, x1 = (x0 + tiles_per_xcd < n_tiles) ? x0 + tiles_per_xcd : n_tiles;
-    if (x0 + j * run >= x1) return;                                      // whole block
+    if (x0 + j * run >= x1 && !(BATCHED && !FAST && p.n_general >= 0)) return;      // whole block
     mecha_lora_key key;
     int key_index = 0;
     int64_t key_end = 0;                                                  // first tile after the key
@@ -786,6 +790,23 @@ __global__ __launch_bounds__(MECHA_BLOCK, 2) void lora_kernel(LoraParams p, int6
     // `run` consecutive tiles per block and turn: fewer key changes per block (a change is a chain of dependent loads and two
     // barriers), at the price of run x as many tiles -- and keys' factors -- in flight per XCD.  SDXL x16 rank-32 batch / one
     // network per key: run 1 9.41 / 4.28 ms, 2 9.23 / 4.13 (the default; MECHA_LORA_RUN), 4 9.65 / 4.02, 8 9.93 / 4.00
+    if constexpr (BATCHED && !FAST) {
+        // The few keys off the fast path, by the host's list: walking every tile of the batch to find them cost 0.5 ms of the
+        // SDXL x16 batch's 9.9 (a key change per visited tile, each a chain of dependent loads and two barriers).
+        if (p.n_general >= 0) {
+            for (int g = 0; g < p.n_general; g++) {
+                __syncthreads();
+                enter_key(p.general_keys[g]);
+                if (fast) continue;                                      // the kernel's own test decides
+                const int64_t tiles_x = (key.cols + LORA_TILE - 1) / LORA_TILE;
+                for (int64_t local = blockIdx.x; local < key_end - key.tile_start; local += gridDim.x) {
+                    __syncthreads();
+                    lora_tile_general<LDT>(p, key, s_nets, key_index, local % tiles_x, local / tiles_x, lds);
+                }
+            }
+            return;
+        }
+    }
     for (int64_t t0 = x0 + j * run; t0 < x1; t0 += nb * run)
     for (int64_t t = t0; t < t0 + run && t < x1; t++) {
         __syncthreads();                                                  // the previous tile's readers of the LDS stages and of s_nets are done
@@ -871,6 +892,7 @@ int mecha_lora_accumulate(const void *base, void *out, int64_t rows, int64_t col
         n++;
     }
     p.key0 = mecha_lora_key{0, rows, cols, 0, 0, n};
+    p.n_general = -1;
     p.n_keys = 1;
     const int64_t tiles = ((cols + LORA_TILE - 1) / LORA_TILE) * ((rows + LORA_TILE - 1) / LORA_TILE);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -890,6 +912,8 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
     MECHA_REQUIRE(keys != nullptr && keys_host != nullptr && nets != nullptr, "NULL key / network table");
     int64_t tiles = 0;
     bool any_fast = nets_host == nullptr, any_general = nets_host == nullptr;     // without the host copy both kernels run
+    LoraParams p{};
+    p.n_general = nets_host != nullptr ? 0 : -1;
     for (int i = 0; i < n_keys; i++) {
         const mecha_lora_key &k = keys_host[i];
         if (nets_host != nullptr) {
@@ -901,6 +925,10 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
             }
             fast = fast && chunks <= MAX_CHUNKS;
             any_fast |= fast; any_general |= !fast;
+            if (!fast && p.n_general >= 0) {
+                if (p.n_general < LORA_MAX_GENERAL) p.general_keys[p.n_general++] = i;
+                else p.n_general = -1;                                   // too many for the list: the general kernel walks all tiles
+            }
         }
         MECHA_REQUIRE(k.rows >= 1 && k.cols >= 1 && k.offset >= 0 && k.net_begin >= 0 && k.net_count >= 0 && k.net_count <= LORA_MAX_NETS,
                       "key %d: bad shape, offset or network range", i);
@@ -908,7 +936,6 @@ int mecha_batched_lora_accumulate(const void *base_arena, void *out_arena, const
                       LORA_TILE, LORA_TILE, (long long)tiles);
         tiles += ((k.cols + LORA_TILE - 1) / LORA_TILE) * ((k.rows + LORA_TILE - 1) / LORA_TILE);
     }
-    LoraParams p{};
     p.base = base_arena; p.out = out_arena; p.base_dt = base_dtype; p.out_dt = out_dtype; p.flags = key_flags;
     p.keys = keys; p.nets = nets; p.n_keys = n_keys;
     hipStream_t s = static_cast<hipStream_t>(stream);
