@@ -560,19 +560,39 @@ class _Wave:
     layout: ArenaLayout
 
 
-def _plan_waves(items: Sequence[Tuple[str, int]], wave_elems: int) -> Tuple[List[_Wave], List[_Wave]]:
+def _plan_waves(items: Sequence[Tuple[str, int]], wave_elems: int, ramp: bool = False) -> Tuple[List[_Wave], List[_Wave]]:
     """(waves, split keys).  Keys (file order) are packed into waves of at most `wave_elems` elements per model.  A key
     LARGER than that window (an embedding of a FLUX / LLM checkpoint under a small staging budget) becomes a wave of its
     own that is moved through the window in pieces of whole rows of elements (SURVEY.md §8e "row-split"; the reference
     instead grows its buffer to the tensor, streaming.py:154-158)."""
     waves, cur, cur_elems, split = [], [], 0, []
+    # `ramp`: the first and the last waves are smaller (a quarter, then half of the window): the pipeline's fill -- nothing runs
+    # on the device before the first wave is staged and copied -- and its drain -- the last wave's D2H copy and file write
+    # overlap nothing -- shrink with them.  Pays for jobs bound by their kernels (SDXL x2 rotate end to end 1.96 -> 1.88 s);
+    # jobs bound by the host side lose to the extra waves (SDXL x4 TIES 0.76 -> 0.83 s, LoRA 0.85 -> 0.87, FLUX stripe equal),
+    # so the caller asks for it per plan.  MECHA_WAVE_RAMP=0 / 1 overrides.
+    ramp = {"0": False, "1": True}.get(os.environ.get("MECHA_WAVE_RAMP", ""), ramp)
+    total = sum((n + 127) // 128 * 128 for _, n in items if n <= wave_elems)
+    done = 0
+
+    def window() -> int:
+        if not ramp:
+            return wave_elems
+        left = total - done
+        head = wave_elems // 4 if done < wave_elems // 4 else wave_elems // 2 if done < 3 * wave_elems // 4 else wave_elems
+        tail = wave_elems // 4 if left <= wave_elems // 4 else wave_elems // 2 if left <= 3 * wave_elems // 4 else wave_elems
+        return max(min(head, tail), 1)
+
+    cap = window()
     for key, n in items:
         if n > wave_elems:
             split.append(_Wave([key], plan_arena([(key, n)])))
             continue
-        if cur and cur_elems + n > wave_elems:
+        if cur and cur_elems + n > cap:                      # a key above a reduced window still gets a wave (of its own)
             waves.append(cur)
+            done += cur_elems
             cur, cur_elems = [], 0
+            cap = window()
         cur.append((key, n))
         cur_elems += (n + 127) // 128 * 128
     if cur:
@@ -804,7 +824,7 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     n_sets = max(1, int(os.environ.get("MECHA_BUFFER_SETS", "2")))
     n_outs = max(n_sets, int(os.environ.get("MECHA_OUT_BUFFERS", str(n_sets + 2))))
     wave_elems = max(max(total_buffer_size, 1 << 16) // (n_sets * n_models * in_esz + n_outs * out_esz), 1024)
-    waves, split_waves = _plan_waves(items, wave_elems)
+    waves, split_waves = _plan_waves(items, wave_elems, ramp=plan.kind == "rotate")
     if not waves and not split_waves:
         return
     # pieces of a split key: whole TIES tiles (4096 elements), as large as the window allows
