@@ -5,7 +5,9 @@
 // scatter list of a wave (file offset -> address inside a pinned staging arena, or the reverse) and the pieces are moved
 // by up to `threads` workers straight between the page cache and pinned memory.  No torch, no HIP: plain POSIX.
 #include <errno.h>
+#include <immintrin.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -50,6 +52,40 @@ int run_team(const std::vector<Piece> &pieces, int threads, F &&one) {
     worker();
     for (auto &t : team) t.join();
     return err.load();
+}
+
+// memcpy whose stores bypass the caches: the output pages are written once and not read again by this process, and an
+// ordinary store to a line that is not cached first READS the line (6.9 GB of SDXL output: 6.9 GB of extra memory traffic
+// beside the staging team's preads).  glibc's memcpy switches to such stores only above ~3/4 of the shared cache per copy;
+// the team's pieces are 4 MiB.  Measured end to end on the GPU box (16 vCPUs): SDXL x4 TIES 0.75-0.82 s against 0.76-0.78 with
+// memcpy, the LoRA job 0.83-0.85 against 0.86-0.88: the first touch of every 4-KiB page of the mapping, not the copy, is what
+// the writer spends its time on.  MECHA_HOST_NT=0: plain memcpy.
+__attribute__((target("avx2"))) void copy_nt_avx2(char *dst, const char *src, size_t n) {
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31;
+    if (head >= n) { memcpy(dst, src, n); return; }
+    memcpy(dst, src, head);
+    dst += head; src += head; n -= head;
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+    }
+    _mm_sfence();
+    memcpy(dst + i, src + i, n - i);
+}
+void copy_out(char *dst, const char *src, size_t n) {
+    static const bool nt = []() {
+        const char *e = getenv("MECHA_HOST_NT");
+        return !(e != nullptr && e[0] == '0') && __builtin_cpu_supports("avx2");
+    }();
+    if (nt && n >= 4096) copy_nt_avx2(dst, src, n);
+    else memcpy(dst, src, n);
 }
 
 }  // namespace
@@ -115,7 +151,7 @@ int mecha_host_mmap_write_many(int fd, const void *const *src, const size_t *nby
     MECHA_REQUIRE(base != MAP_FAILED, "mmap of the output file failed: %s", strerror(errno));
     const std::vector<Piece> pieces = split(nbytes, n);
     run_team(pieces, threads, [&](const Piece &p) -> int {
-        memcpy(static_cast<char *>(base) + (offsets[p.entry] - map_lo) + p.skip, static_cast<const char *>(src[p.entry]) + p.skip, p.len);
+        copy_out(static_cast<char *>(base) + (offsets[p.entry] - map_lo) + p.skip, static_cast<const char *>(src[p.entry]) + p.skip, p.len);
         return 0;
     });
     MECHA_REQUIRE(munmap(base, (size_t)(hi - map_lo)) == 0, "munmap failed: %s", strerror(errno));
