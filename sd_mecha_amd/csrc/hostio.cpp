@@ -59,7 +59,7 @@ int run_team(const std::vector<Piece> &pieces, int threads, F &&one) {
 // beside the staging team's preads).  glibc's memcpy switches to such stores only above ~3/4 of the shared cache per copy;
 // the team's pieces are 4 MiB.  Measured end to end on the GPU box (16 vCPUs): SDXL x4 TIES 0.75-0.82 s against 0.76-0.78 with
 // memcpy, the LoRA job 0.83-0.85 against 0.86-0.88: the first touch of every 4-KiB page of the mapping, not the copy, is what
-// the writer spends its time on.  MECHA_HOST_NT=0: plain memcpy.
+// the writer spends its time on, and the runs with these stores spread wider (up to 0.88 s).  Off unless MECHA_HOST_NT=1.
 __attribute__((target("avx2"))) void copy_nt_avx2(char *dst, const char *src, size_t n) {
     const size_t head = (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31;
     if (head >= n) { memcpy(dst, src, n); return; }
@@ -82,7 +82,7 @@ __attribute__((target("avx2"))) void copy_nt_avx2(char *dst, const char *src, si
 void copy_out(char *dst, const char *src, size_t n) {
     static const bool nt = []() {
         const char *e = getenv("MECHA_HOST_NT");
-        return !(e != nullptr && e[0] == '0') && __builtin_cpu_supports("avx2");
+        return e != nullptr && e[0] == '1' && __builtin_cpu_supports("avx2");
     }();
     if (nt && n >= 4096) copy_nt_avx2(dst, src, n);
     else memcpy(dst, src, n);

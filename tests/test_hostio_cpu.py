@@ -99,3 +99,31 @@ def test_writer_put_many_matches_put(tmp_path):
     assert ra.file_metadata() == rb.file_metadata() == {"mecha_recipe": "recipe"}
     for k, t in tensors.items():
         assert torch.equal(ra[k], t) and torch.equal(rb[k], t)
+
+
+def test_mmap_write_many_with_cache_bypassing_stores(tmp_path):
+    """MECHA_HOST_NT=1 (read once per process, hence the child): the writer's copy through non-temporal stores, with pieces
+    that start and end off the 32-byte grid."""
+    import subprocess
+    import sys
+    code = f"""
+import os, numpy as np
+from sd_mecha_amd import _lib
+L = _lib.lib()
+src = np.random.default_rng(3).integers(0, 256, size=9_000_000, dtype=np.uint8)
+fd = os.open({str(tmp_path / 'nt.bin')!r}, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+os.ftruncate(fd, 9_500_000)
+plan = [(0, 5_000_003, 17), (5_000_003, 3_999_990, 5_100_001), (8_999_993, 7, 9_400_000)]
+srcs = np.ascontiguousarray([src.ctypes.data + s for s, _, _ in plan], dtype=np.uint64)
+sizes = np.ascontiguousarray([n for _, n, _ in plan], dtype=np.uint64)
+offs = np.ascontiguousarray([o for _, _, o in plan], dtype=np.int64)
+_lib.check(L.mecha_host_mmap_write_many(fd, srcs.ctypes.data, sizes.ctypes.data, offs.ctypes.data, len(plan), 4), "mmap write")
+os.close(fd)
+got = np.fromfile({str(tmp_path / 'nt.bin')!r}, dtype=np.uint8)
+want = np.zeros(9_500_000, dtype=np.uint8)
+for s, n, o in plan:
+    want[o:o + n] = src[s:s + n]
+assert np.array_equal(got, want)
+"""
+    env = dict(os.environ, MECHA_HOST_NT="1", PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=120)
