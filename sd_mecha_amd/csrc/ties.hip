@@ -217,8 +217,10 @@ __device__ __forceinline__ uint32_t bracket_bin(uint32_t t, uint32_t shift, uint
     return ((t + low_mask) >> shift) + (t >> shift);              // ceil(t / 2^shift) + floor(t / 2^shift) = 2q + (remainder != 0)
 }
 
+// Three 16-bit deltas (the SDXL x4 job; the second group of a FLUX x8 stripe) fit 5 waves per SIMD (95 VGPRs; the CAP = 4
+// instantiation needs 115 and spills 168 when forced): count pass 5.11 -> 4.97 ms (SDXL), 2 x 2.4 -> 4.6 ms (FLUX stripe).
 template <int CAP, bool W32>
-__global__ __launch_bounds__(MECHA_BLOCK) void ties_count_kernel(TiesParams p, int d0, int nd) {
+__global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_count_kernel(TiesParams p, int d0, int nd) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * TIES_BINS words, then 2 * CAP counters
     uint32_t *lds_cnt = lds_hist + nd * TIES_BINS;
     const uint32_t dump = nd * TIES_BINS + 2 * CAP + (threadIdx.x & 63);   // 64 write-only words after the counters
@@ -988,6 +990,8 @@ __device__ __forceinline__ int sign_i32(int v) {
 // E: elements per lane.  8 (16-byte accesses) up to 4 deltas; 4 (8-byte accesses) for 5..8 deltas: with 8 elements the state of 8
 // input streams costs 180-228 VGPRs (2 waves per SIMD, 0.61 of 8 TB/s on the FLUX x8 stripe) whatever the source order -- the
 // scheduler hoists every model's unpack and subtraction to the front; half the elements is half the registers.
+// (5 waves per SIMD by launch bounds -- 96 VGPRs, 2 spilled with 3 models, 11 with 7 -- measured slower: 5.9 against 5.5 ms
+//  on the SDXL x4 job, 6.7 against 4.7 on the FLUX stripe)
 template <int N, int DT, int ODT, int E>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
     constexpr int P = E / 2;                       // pairs per lane
@@ -1586,11 +1590,12 @@ void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
     for (int d0 = 0; d0 < p.n_deltas; d0 += COUNT_GROUP) {
         const int nd = (p.n_deltas - d0 < COUNT_GROUP) ? p.n_deltas - d0 : COUNT_GROUP;
         // LDS: nd histograms, 2 * CAP counters, 64 dump words
-        const int cap = nd <= 2 ? 2 : (nd <= 4 ? 4 : 8);
+        const int cap = nd <= 2 ? 2 : (nd <= 3 ? 3 : (nd <= 4 ? 4 : 8));
         const size_t lds = ((size_t)nd * TIES_BINS + 2 * cap + 64) * sizeof(uint32_t);
         const bool w32 = p.in_dt == MECHA_F32;
 #define MECHA_COUNT_LAUNCH(CAP_, W32_) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd)
         if (cap == 2) { if (w32) MECHA_COUNT_LAUNCH(2, true); else MECHA_COUNT_LAUNCH(2, false); }
+        else if (cap == 3) { if (w32) MECHA_COUNT_LAUNCH(3, true); else MECHA_COUNT_LAUNCH(3, false); }
         else if (cap == 4) { if (w32) MECHA_COUNT_LAUNCH(4, true); else MECHA_COUNT_LAUNCH(4, false); }
         else { if (w32) MECHA_COUNT_LAUNCH(8, true); else MECHA_COUNT_LAUNCH(8, false); }
 #undef MECHA_COUNT_LAUNCH
