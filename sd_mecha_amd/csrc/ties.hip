@@ -344,6 +344,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_
     const long long q0 = 2 * t0, q1 = 2 * t1;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    // (one slot and no prefetch is 80 VGPRs, 6 waves per SIMD for three deltas: 5.08 ms against 4.95 with this pipeline at 5 waves)
     if (q0 < q1) issue(q0, S0{});
     for (long long q = q0; q < q1; q += 2) {                             // q0 and q1 are even: positions come in pairs
         issue(q + 1, S1{});
