@@ -1616,7 +1616,7 @@ void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float 
 
 template <int N, int DT>
 void launch_merge_full(const TiesParams &p, const MergeExtra &x, unsigned /*looped_grid*/, void *out, uint32_t *flags, hipStream_t s) {
-    constexpr int E = N <= 4 ? 8 : 4;                             // elements per lane (see the kernel)
+    constexpr int E = N <= 4 ? 8 : 4;                             // elements per lane (see the kernel; 4 for three models: 5.6-5.8 against 5.5 ms)
     const unsigned grid = (unsigned)(p.total_tiles * (TIES_TILE / (MECHA_BLOCK * E)));          // flat: one block per 256 x E elements
     if (p.out_dt == MECHA_BF16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_BF16, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
     else if (p.out_dt == MECHA_F16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F16, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
