@@ -103,7 +103,7 @@ def run_rotate_batched(args, device):
             # + 14 more for the keys that failed it (counted from the second solve's words)
             fl = len(idx) * rotate_flops_run(n, p, (len(idx) - short_ok) / len(idx) if n < p else 0.0)
             per_group.append({"shape": [n, p], "keys": len(idx), "ms": round(dt * 1e3, 2), "tflops": round(fl / dt / 1e12, 1),
-                              **({"left_after_short_schedule": short_ok} if n < p else {})})
+                              **({"converged_after_short_schedule": short_ok} if n < p else {})})
             t_total += dt
             flops_total += fl
     done_bytes = layout.payload_elems * 2 * 3
