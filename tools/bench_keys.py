@@ -48,8 +48,8 @@ def polar_step_flops(r, c):
 
 def rotate_flops_run(n, p, wide_keys_through_long_schedule=0.0):
     """GEMM flops of one key on the batched path.  Tall: A^T B, 14 polar steps on p x p, the application.  Wide: two polar
-    solves of 6 steps + the Gram matrix of the convergence test (+ 14 steps for the given fraction of keys), five
-    n x n x p products."""
+    solves of 6 steps + the Gram matrix of the convergence test (+ 14 steps for the given
+    fraction of keys), five n x n x p products."""
     if n >= p:
         return 4 * n * p * p + 14 * polar_step_flops(p, p)
     nt = -(-n // 128)
