@@ -5,7 +5,6 @@ Replaces the per-key tensors the reference's executor creates one future at a ti
 """
 from __future__ import annotations
 
-import ctypes
 from dataclasses import dataclass
 from typing import List, Sequence, Tuple
 

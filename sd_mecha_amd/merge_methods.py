@@ -22,7 +22,7 @@ from typing import Mapping, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F16, F32, FLAG_INPUT_NONFINITE, FLAG_OUTPUT_NONFINITE
+from ._lib import BF16, F16, F32, FLAG_INPUT_NONFINITE
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 

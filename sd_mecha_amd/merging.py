@@ -38,7 +38,7 @@ from . import lora as lora_mod
 from . import merge_methods as mm
 from . import model_configs
 from .arena import ArenaLayout, plan_arena, shard_keys_lpt
-from .merge_methods import NonFiniteStateDictKeyError, StateDictKeyError
+from .merge_methods import StateDictKeyError
 from .recipe_nodes import LiteralRecipeNode, MergeRecipeNode, ModelRecipeNode, RealizedKeyRelation, RecipeNode, serialize, value_to_node
 from .streaming import DTYPE_REVERSE_MAPPING, InSafetensorsDict, OutSafetensorsDict, TensorMetadata, compact_holes, tensor_bytes
 
