@@ -265,6 +265,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, float *
 // read feeds two MFMAs and a wave has four independent accumulator chains, so one or two blocks per CU keep the matrix
 // pipes fed (the 64 x 64 kernel: one dependent chain per wave, 400 small blocks for a 1280 x 1280 product).  16-deep
 // k-chunks: 2 operands x 2 buffers x 16 x 132 floats = 33 KiB of LDS.
+#ifndef MECHA_ROT_XCD_MAP
+#define MECHA_ROT_XCD_MAP 1
+#endif
 constexpr int GK2 = 16;
 constexpr int GP2 = 132;               // LDS row pitch in floats (528 B: 16-byte aligned rows, rows 4 banks apart)
 
@@ -335,13 +338,23 @@ template <int LA, int LB>
 __global__ __launch_bounds__(256, 3) void gemm128_kernel(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab, int n_slabs, Batch bt,
                                                       GemmEpilogue e, int symmetric) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][GK2 * GP2];     // [buffer][A | B]
-    const int key = blockIdx.z / n_slabs, slab = blockIdx.z - key * n_slabs;
-    if (symmetric && blockIdx.x < blockIdx.y) return;
+    // Workgroups go to the 8 XCDs round-robin by their linear id, each XCD with an L2 of its own: XCD x takes a CONTIGUOUS
+    // range of the launch's tiles (x fastest, then y, then key and slab), so that the tiles of one key -- which read the
+    // same operand panels at about the same time -- share one L2 instead of pulling every panel into all eight.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (MECHA_ROT_XCD_MAP) {
+        const uint64_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint64_t id = bx + gx * (by + gy * (uint64_t)bz), xcd = id & 7u;
+        const uint64_t logical = xcd * (total >> 3) + (xcd < (total & 7u) ? xcd : (total & 7u)) + (id >> 3);
+        bx = (unsigned)(logical % gx); by = (unsigned)((logical / gx) % gy); bz = (unsigned)(logical / (gx * gy));
+    }
+    const int key = bz / n_slabs, slab = bz - key * n_slabs;
+    if (symmetric && bx < by) return;
     if (bt.skip != nullptr && bt.skip[key] != 0u) return;
     A.p = key_ptr(A.p, bt, key); B.p = key_ptr(B.p, bt, key); C = key_ptr(C, bt, key);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kk = lane >> 5;
-    const int64_t bm0 = (int64_t)blockIdx.y * 128, bn0 = (int64_t)blockIdx.x * 128;
+    const int64_t bm0 = (int64_t)by * 128, bn0 = (int64_t)bx * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int64_t k_begin = (int64_t)slab * k_per_slab;
     const int64_t k_end = (k_begin + k_per_slab < K) ? k_begin + k_per_slab : K;
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(256, 3) void gemm128_kernel(Operand A, Operand B, f
     if (n_slabs > 1) ee = GemmEpilogue{};                       // the epilogue then runs in gemm_reduce
     bool bad = false;
     if (symmetric) {
-        const bool mirror = blockIdx.x > blockIdx.y;
+        const bool mirror = bx > by;
         const bool vec = (N & 3) == 0;
 #pragma unroll
         for (int tm = 0; tm < 2; tm++)
