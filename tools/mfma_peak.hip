@@ -2,9 +2,10 @@
 // v_mfma_f32_32x32x2_f32 from registers (4 independent accumulators per wave, as rotate.hip's GEMM), 1 to 4 waves per SIMD.
 // The rotate GEMM's roofline fraction is quoted against 157.3 TFLOP/s (256 CUs x 4 SIMDs x 64 flop / cycle x 2.4 GHz); this
 // probe shows how much of that a pure MFMA stream reaches (clocks under matrix load included).
-//   hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak [launch length multiplier]
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void spin(float *out, int iters, float a0, float b0) {
     f32x16 acc[4];
@@ -20,12 +21,13 @@ __global__ __launch_bounds__(256) void spin(float *out, int iters, float a0, flo
     for (int j = 0; j < 4; j++) for (int i = 0; i < 16; i++) s += acc[j][i];
     if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-int main() {
+int main(int argc, char **argv) {
+    const int mult = argc > 1 ? atoi(argv[1]) : 1;      // longer launches: what the pipes sustain once the power limit acts
     float *out; hipMalloc(&out, 1 << 24);
     int cus = 256; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int blocks_per_cu = 1; blocks_per_cu <= 4; blocks_per_cu++) {
-        const int grid = cus * blocks_per_cu, iters = 4096;
+        const int grid = cus * blocks_per_cu, iters = 4096 * mult;
         spin<<<grid, 256>>>(out, 64, 1.0f, 1.0f);
         hipDeviceSynchronize();
         float best = 1e30f;
