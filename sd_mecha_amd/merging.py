@@ -78,10 +78,11 @@ def _bound(node: MergeRecipeNode) -> Dict[str, RecipeNode]:
 
 def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
     """Recognise the node chains of SURVEY.md §3.2-3.3 (wrappers.py shapes); None = evaluate generically."""
+    lora_mod.bind_bases(recipe)
     chain = lora_mod.parse_chain(recipe)
     if chain is not None:                                                     # SURVEY.md §3.4: base + sum of LoRA deltas
-        expr, base, loras = chain
-        return FusedPlan("lora", [base], {"expr": expr, "loras": loras})
+        expr, base, loras, prefixes = chain
+        return FusedPlan("lora", [base], {"expr": expr, "loras": loras, "prefixes": prefixes})
     fallback = None
     if isinstance(recipe, MergeRecipeNode) and recipe.merge_method.identifier == "fallback":
         a, d = recipe.args[0], recipe.args[1] if len(recipe.args) > 1 else recipe.kwargs.get("default")
@@ -158,6 +159,8 @@ def collect_models(recipe: RecipeNode) -> List[ModelRecipeNode]:
                 walk(a)
             for a in n.kwargs.values():
                 walk(a)
+            if getattr(n, "lora_base", None) is not None:                       # convert(lora, base): the base is no argument
+                walk(n.lora_base)
     walk(recipe)
     return out
 
@@ -173,7 +176,7 @@ def _lora_file_nodes(recipe: RecipeNode) -> set:
             if id(n) in visited:
                 return
             visited.add(id(n))
-            conv = n.merge_method.identifier == "convert_lora_to_base"
+            conv = lora_mod.is_conversion(n)
             for i, a in enumerate(n.args):
                 walk(a, conv and i == 0)
             for a in n.kwargs.values():
@@ -189,6 +192,7 @@ class _LoraStore:
 
     def __init__(self, plan: FusedPlan, readers, device: torch.device, host_threads: int):
         self.expr = plan.params["expr"]
+        self.prefixes = list(plan.params.get("prefixes") or [lora_mod.PREFIX] * len(plan.params["loras"]))
         self.files = []
         self._hosts = []                                         # pinned staging buffers, until their copies are done
         self.tables_by_file: List[dict] = []
@@ -276,12 +280,12 @@ class _LoraStore:
         n_files = len(self.files)
         for index, (key, off, n) in enumerate(zip(layout.keys, layout.offsets, layout.numels)):
             shape = tuple(header[key].shape)
-            prefix = lora_mod.lora_key_prefix(key, shape)
-            found = [self.tables_by_file[i].get(prefix) if prefix is not None else None for i in range(n_files)]
-            if prefix is not None:
+            stem = lora_mod.lora_key_prefix(key, shape, True, "")       # "_<stem>": each file's flavour prefix goes in front
+            found = [self.tables_by_file[i].get(self.prefixes[i] + stem) if stem is not None else None for i in range(n_files)]
+            if stem is not None:
                 for i in range(n_files):                            # anything the fast table left out goes the careful way
-                    if found[i] is None and f"{prefix}.{lora_mod.UP}" in self.files[i][0]:
-                        lora_mod.network_entries(self.files[i][0], prefix)       # raises for Tucker networks
+                    if found[i] is None and f"{self.prefixes[i]}{stem}.{lora_mod.UP}" in self.files[i][0]:
+                        lora_mod.network_entries(self.files[i][0], self.prefixes[i] + stem)       # raises for Tucker networks
             try:
                 applied = lora_mod.networks_for_key(self.expr, lambda i: found[i] is not None)
             except StateDictKeyError:
@@ -315,15 +319,15 @@ class _LoraStore:
         out, skip = [], set()
         for index, (key, off, n) in enumerate(zip(layout.keys, layout.offsets, layout.numels)):
             shape = tuple(header[key].shape)
-            prefix = lora_mod.lora_key_prefix(key, shape)
+            stem = lora_mod.lora_key_prefix(key, shape, True, "")
             found = {}
 
-            def has(i, prefix=prefix, found=found):
-                if prefix is None:
+            def has(i, stem=stem, found=found):
+                if stem is None:
                     return False
                 if i not in found:
                     try:
-                        found[i] = lora_mod.network_entries(self.files[i][0], prefix)
+                        found[i] = lora_mod.network_entries(self.files[i][0], self.prefixes[i] + stem)
                     except StateDictKeyError:
                         found[i] = None
                 return found[i] is not None
@@ -391,7 +395,7 @@ class GraphInfo:
                 out = {k: (tuple(v.shape) if isinstance(v, torch.Tensor) else ()) for k, v in node.value.items()}
         elif isinstance(node, MergeRecipeNode):
             ident = node.merge_method.identifier
-            inputs = [self.keys(a) for a in (*node.args, *node.kwargs.values())]
+            inputs = [] if lora_mod.is_conversion(node) else [self.keys(a) for a in (*node.args, *node.kwargs.values())]
             if ident == "fallback":
                 out = {}
                 for ks in inputs:
@@ -400,11 +404,11 @@ class GraphInfo:
                         break
                     for k, shape in ks.items():
                         out.setdefault(k, shape)
-            elif ident == "convert_lora_to_base":
-                lora_reader, base_reader = self.readers[id(node.args[0])], self.readers[id(node.args[1])]
+            elif lora_mod.is_conversion(node):
+                lora_reader, base_reader = self.readers[id(node.args[0])], self.readers[id(lora_mod.base_of(node))]
                 out = {}
                 for k, m in base_reader.metadata():
-                    prefix = lora_mod.lora_key_prefix(k, m.shape, m.dtype.is_floating_point)
+                    prefix = lora_mod.lora_key_prefix(k, m.shape, m.dtype.is_floating_point, node.merge_method.lora_prefix)
                     if prefix is not None and f"{prefix}.{lora_mod.UP}" in lora_reader and f"{prefix}.{lora_mod.DOWN}" in lora_reader:
                         out[k] = m.shape
             else:
@@ -660,6 +664,7 @@ def merge(
     backend = backend or HipBackend(merge_device)
     rank, world, dist = _dist_info()
 
+    lora_mod.bind_bases(recipe)
     models = collect_models(recipe)
     if not models:
         raise ValueError("the recipe has no model inputs")
@@ -1222,10 +1227,10 @@ class _KeyRun:
         node_keys = ex.info.keys(node)
         if node_keys is not None and key not in node_keys:                     # merging.py:412-414
             raise StateDictKeyError(key)
-        if method.identifier == "convert_lora_to_base":                        # LycorisToBase.__call__ (lycoris.py:69-85)
-            lora_node, base_node = node.args
+        if lora_mod.is_conversion(node):                                       # LycorisToBase.__call__ (lycoris.py:69-85)
+            lora_node, base_node = node.args[0], lora_mod.base_of(node)
             reader, meta = ex.readers[id(lora_node)], ex.readers[id(base_node)].meta(key)
-            prefix = lora_mod.lora_key_prefix(key, tuple(meta.shape), meta.dtype.is_floating_point)
+            prefix = lora_mod.lora_key_prefix(key, tuple(meta.shape), meta.dtype.is_floating_point, method.lora_prefix)
             if prefix is None:
                 raise StateDictKeyError(key)
             up_k, down_k, alpha_k = lora_mod.network_entries(reader, prefix)

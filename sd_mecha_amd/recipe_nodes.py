@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import inspect
 import pathlib
+import re
 from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Tuple
 
 
@@ -315,12 +316,13 @@ def serialize(recipe: RecipeNode, model_configs: Optional[Mapping[int, str]] = N
         raise TypeError(f"type {type(v)} cannot be serialized: {v}")
 
     done: Dict[int, str] = {}                   # recipes are DAGs: each node is visited once
+    aux_configs: Dict[int, str] = {}            # LoRA files: the config their conversion method is registered for (lycoris.py:115-117)
 
     def node(n: RecipeNode) -> str:
         if id(n) in done:
             return done[id(n)]
         if isinstance(n, ModelRecipeNode):
-            config = (model_configs or {}).get(id(n)) or n.config or "structural"
+            config = (model_configs or {}).get(id(n)) or n.config or aux_configs.get(id(n)) or "structural"
             ref = add(f"model {value(str(n.path))} model_config={value(config)} merge_space=\"weight\"")
         elif isinstance(n, LiteralRecipeNode):
             if isinstance(n.value, Mapping):
@@ -329,6 +331,8 @@ def serialize(recipe: RecipeNode, model_configs: Optional[Mapping[int, str]] = N
                 lit = add(f"literal {value({'key': n.value})} model_config=\"singleton-mecha\" merge_space=\"param\"")
                 ref = add(f"merge \"convert_singleton\" {lit}")
         elif isinstance(n, MergeRecipeNode):
+            if getattr(n.merge_method, "lora_config", None) and n.args:
+                aux_configs[id(n.args[0])] = n.merge_method.lora_config
             parts = ["merge", value(n.merge_method.identifier)] + [value(a) for a in n.args] + [f"{k}={value(v)}" for k, v in n.kwargs.items()]
             ref = add(" ".join(parts))
         else:
@@ -340,40 +344,70 @@ def serialize(recipe: RecipeNode, model_configs: Optional[Mapping[int, str]] = N
     return "\n".join([f"version {MECHA_FORMAT_VERSION}"] + instructions)
 
 
-def _tokenize(line: str) -> List[str]:
-    """serialization.py:100-132: split at blanks outside quotes; a quoted string keeps its quotes (and a ``name=`` prefix)."""
-    tokens, cur, prefix, inside, escape = [], [], [], False, False
-    for ch in line:
-        if escape:
-            escape = False
-        elif ch == "\\":
-            escape = True
-            continue
-        elif ch == '"':
-            inside = not inside
-            if inside:
-                prefix, cur = cur, []
-            else:
-                tokens.append("".join(prefix) + '"' + "".join(cur) + '"')
-                cur, prefix = [], []
-            continue
-        elif ch == " " and not inside:
-            if cur:
-                tokens.append("".join(cur))
-                cur = []
-            continue
-        cur.append(ch)
-    if inside:
-        raise ValueError("mismatched quotes in input")
-    if cur:
-        tokens.append("".join(cur))
-    return tokens
+# The `.mecha` line grammar (format 0.1.0), as this parser reads it:
+#     line   := command { blank arg }            command := dict | literal | model | merge
+#     arg    := [ name "=" ] value               name    := any run of characters without blank, quote or "="
+#     value  := string | "&" index | null | true | false | number
+#     string := '"' { "\" any-char | any char but '"' and "\" } '"'          (a backslash keeps the next character as it is)
+#     number := a python float literal if it holds "." or an exponent, else a python int literal
+# Blank lines and lines that start with "#" are skipped; "&n" names the result of instruction n (0-based, earlier lines only).
+_ARG = re.compile(r"""
+    \s*
+    (?: (?P<name> [^\s"=]+ ) = (?= \S ) )?          # optional  name=
+    (?: " (?P<string> (?: \\. | [^"\\] )* ) "       # a quoted string ...
+      | (?P<bare> [^\s"]+ ) )                       # ... or a bare word: reference, constant or number
+    (?= \s | $ )
+""", re.VERBOSE | re.DOTALL)
+_UNESCAPE = re.compile(r"\\(.)", re.DOTALL)
+_NUMBER_AS_FLOAT = re.compile(r"[.eE]")
+
+
+def _scan(line: str):
+    """One instruction line -> (command, [(name or None, kind, text)]) with kind in {"string", "bare"}."""
+    pos, out = 0, []
+    end = len(line.rstrip())
+    while pos < end:
+        m = _ARG.match(line, pos)
+        if m is None:
+            raise ValueError("mismatched quotes in input" if '"' in line[pos:] else f"cannot read {line[pos:].strip()!r}")
+        if m.group("string") is not None:
+            out.append((m.group("name"), "string", _UNESCAPE.sub(r"\1", m.group("string"))))
+        else:
+            out.append((m.group("name"), "bare", m.group("bare")))
+        pos = m.end()
+    if not out or out[0][0] is not None or out[0][1] != "bare":
+        raise ValueError("expected a command")
+    return out[0][2], out[1:]
+
+
+def _cmd_dict(positional, named):
+    return dict(*positional, **named)
+
+
+def _cmd_literal(positional, named):
+    return LiteralRecipeNode(positional[0])
+
+
+def _cmd_model(positional, named):
+    config = named.get("model_config")
+    return ModelRecipeNode(pathlib.Path(positional[0]), None if config in (None, "structural") else config)
+
+
+def _cmd_merge(positional, named):
+    method, *rest = positional
+    if method == "convert_singleton":           # the three-line spelling of a python scalar (serialize() above): back to the scalar
+        lit = rest[0]
+        inner = lit.value if isinstance(lit, LiteralRecipeNode) else lit
+        return LiteralRecipeNode(inner["key"]) if isinstance(inner, Mapping) and "key" in inner else value_to_node(inner)
+    return resolve(method)(*rest, **named)
+
+
+_COMMANDS = {"dict": _cmd_dict, "literal": _cmd_literal, "model": _cmd_model, "merge": _cmd_merge}
 
 
 def deserialize(recipe) -> RecipeNode:
-    """Recreate a recipe graph from `.mecha` text (serialization.py:26-140): ``dict`` / ``literal`` / ``model`` / ``merge``
-    lines, ``&n`` back references, ``#`` comments.  Methods are looked up by identifier in this package's registry;
-    ``convert_singleton`` of a literal ``{"key": v}`` is the scalar ``v``."""
+    """Recreate a recipe graph from `.mecha` text (the format serialization.py:26-140 reads; grammar above).  Methods are
+    looked up by identifier in this package's registry; ``convert_singleton`` of a literal ``{"key": v}`` is the scalar ``v``."""
     lines = recipe.split("\n") if not isinstance(recipe, list) else recipe
     if not lines or not lines[0].startswith("version"):
         raise RuntimeError("bad format: expected version at line 1")
@@ -381,53 +415,33 @@ def deserialize(recipe) -> RecipeNode:
         raise RuntimeError(f"bad recipe version: got {lines[0]}, expected version {MECHA_FORMAT_VERSION}")
     results: List[Any] = []
 
-    def arg_value(arg: str, index: int):
+    def value(kind: str, text: str, index: int):
+        if kind == "string":
+            return text
+        if text in _CONSTANTS:
+            return _CONSTANTS[text]
         try:
-            if arg in _CONSTANTS:
-                return _CONSTANTS[arg]
-            if arg.startswith("&"):
-                ref = int(arg[1:])
-                if ref < 0 or ref >= len(results):
-                    raise ValueError(f"reference {arg} out of bounds")
+            if text[0] == "&":
+                ref = int(text[1:])
+                if not 0 <= ref < len(results):
+                    raise ValueError(f"reference {text} out of bounds")
                 return results[ref]
-            if arg.startswith('"') and arg.endswith('"'):
-                return arg[1:-1]
-            if "." in arg or "e" in arg.lower():
-                return float(arg)
-            return int(arg)
+            return float(text) if _NUMBER_AS_FLOAT.search(text) else int(text)
         except ValueError as e:
-            raise ValueError(f"argument {index}: {e}")
+            raise ValueError(f"argument {index}: {e}") from None
 
     for line_num, line in enumerate(lines[1:], 2):
         line = line.strip()
-        if not line or line.startswith("#"):
+        if not line or line[0] == "#":
             continue
         try:
-            command, *args = _tokenize(line)
-            positional, named = [], {}
-            for i, arg in enumerate(args):
-                if "=" in arg and not arg.startswith('"'):
-                    k, v = arg.split("=", 1)
-                    named[k] = arg_value(v, i)
-                else:
-                    positional.append(arg_value(arg, i))
-            if command == "dict":
-                results.append(dict(*positional, **named))
-            elif command == "literal":
-                results.append(LiteralRecipeNode(positional[0]))
-            elif command == "model":
-                config = named.get("model_config")
-                results.append(ModelRecipeNode(pathlib.Path(positional[0]), None if config in (None, "structural") else config))
-            elif command == "merge":
-                method, *positional = positional
-                if method == "convert_singleton":
-                    lit = positional[0]
-                    inner = lit.value if isinstance(lit, LiteralRecipeNode) else lit
-                    results.append(LiteralRecipeNode(inner["key"]) if isinstance(inner, Mapping) and "key" in inner else value_to_node(inner))
-                else:
-                    results.append(resolve(method)(*positional, **named))
-            else:
+            command, args = _scan(line)
+            handler = _COMMANDS.get(command)
+            if handler is None:
                 raise ValueError(f"unknown command: {command}")
+            positional = [value(kind, text, i) for i, (name, kind, text) in enumerate(args) if name is None]
+            named = {name: value(kind, text, i) for i, (name, kind, text) in enumerate(args) if name is not None}
+            results.append(handler(positional, named))
         except ValueError as e:
-            raise ValueError(f"line {line_num}: {e}.\n    {line}")
+            raise ValueError(f"line {line_num}: {e}.\n    {line}") from None
     return results[-1]

@@ -423,8 +423,12 @@ def gen_mecha_text(_out):
         kshapes = {"unet.out.2.weight": (4, 320, 3, 3), "unet.out.2.bias": (4,)}
         for name in ("ka", "kb"):
             safetensors.torch.save_file({k: torch.randn(s, generator=g).to(torch.bfloat16) for k, s in kshapes.items()}, str(td / f"{name}.safetensors"))
+        safetensors.torch.save_file({"lora_unet_out_2.lora_up.weight": (torch.randn(4, 2, generator=g) * 0.05).half(),
+                                     "lora_unet_out_2.lora_down.weight": (torch.randn(2, 320, 3, 3, generator=g) * 0.05).half(),
+                                     "lora_unet_out_2.alpha": torch.tensor(1.0).half()}, str(td / "lora0.safetensors"))
         ms = [sd_mecha.model(td / f"m{m}.safetensors") for m in range(3)]
         ka, kb = (sd_mecha.model(td / f"{n}.safetensors", config="sdxl-kohya") for n in ("ka", "kb"))
+        lora_delta = sd_mecha.convert(sd_mecha.model(td / "lora0.safetensors"), ka)     # convert_'sdxl-kohya_kohya_lora'_to_base (lycoris.py:52)
         kw = dict(threads=0, output_dtype=torch.bfloat16, tqdm=quiet)
         d = [linear.subtract(m, ms[0]) for m in ms[1:]]
         recipes = {
@@ -437,6 +441,7 @@ def gen_mecha_text(_out):
             "operators": (ms[0] + (ms[1] - ms[0]) * 0.5, {}),
             "slerp": (linear.slerp(ms[0], ms[1], alpha=0.3), {}),
             "known_config": (linear.weighted_sum(ka, kb, alpha=0.25), {}),
+            "lora": (linear.add_difference(ka, lora_delta, alpha=0.75) | ka, {}),
         }
         for name, (r, extra) in recipes.items():
             res = sd_mecha.merge(r, **kw, **extra)

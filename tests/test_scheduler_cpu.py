@@ -121,7 +121,7 @@ def test_arena_layout_and_lpt_sharding():
     from sd_mecha_amd.arena import ALIGN_ELEMS, plan_arena, shard_keys_lpt
     from sd_mecha_amd.shapes import load_manifest, numel
     items = [(k, numel(s)) for k, s, _ in load_manifest("sdxl-sgm")]
-    assert len(items) == 2531 and sum(n for _, n in items) == 3_468_849_947 + 0 or True
+    assert len(items) == 2531 and sum(n for _, n in items) == 3_468_849_947
     L = plan_arena(items)
     assert all(o % ALIGN_ELEMS == 0 for o in L.offsets)
     ends = [o + n for o, n in zip(L.offsets, L.numels)]
@@ -170,6 +170,7 @@ def _mecha_recipes(amd, d):
         "operators": (ms[0] + (ms[1] - ms[0]) * 0.5, {}),
         "slerp": (amd.slerp(ms[0], ms[1], alpha=0.3), {}),
         "known_config": (amd.weighted_sum(ka, kb, alpha=0.25), {}),
+        "lora": (amd.add_difference(ka, amd.convert(amd.model(str(d / "lora0.safetensors")), ka), alpha=0.75) | ka, {}),
     }
 
 
@@ -189,8 +190,12 @@ def test_mecha_text_equals_the_references(tmp_path):
     for n in ("ka", "kb"):
         safetensors.torch.save_file({"unet.out.2.weight": torch.randn(4, 320, 3, 3, generator=g).to(torch.bfloat16),
                                      "unet.out.2.bias": torch.randn(4, generator=g).to(torch.bfloat16)}, str(tmp_path / f"{n}.safetensors"))
+    safetensors.torch.save_file({"lora_unet_out_2.lora_up.weight": (torch.randn(4, 2, generator=g) * 0.05).half(),
+                                 "lora_unet_out_2.lora_down.weight": (torch.randn(2, 320, 3, 3, generator=g) * 0.05).half(),
+                                 "lora_unet_out_2.alpha": torch.tensor(1.0).half()}, str(tmp_path / "lora0.safetensors"))
     recipes = _mecha_recipes(amd, tmp_path)
     assert sorted(recipes) == sorted(want)
+    assert "convert_'sdxl-kohya_kohya_lora'_to_base" in want["lora"]            # the reference's identifier (lycoris.py:52)
     be = OracleBackend()
     for name, (recipe, extra) in recipes.items():
         expect = want[name].replace("<DIR>", str(tmp_path))
@@ -198,12 +203,16 @@ def test_mecha_text_equals_the_references(tmp_path):
             res = amd.merge(recipe, backend=be, output_dtype=torch.bfloat16, threads=0, **extra)
             assert res["__metadata__"]["mecha_recipe"] == expect, name
         config = {"known_config": "sdxl-kohya"}.get(name)
+        if name == "lora":                                                   # the deserialized conversion finds its base at merge time
+            res2 = amd.merge(again_lora := amd.deserialize(expect), backend=be, output_dtype=torch.bfloat16, threads=0)
+            assert all(torch.equal(res[k], res2[k]) for k in res if k != "__metadata__") and fuse(again_lora).kind == "lora"
         text = amd.serialize(recipe)
         assert text == expect, name                                          # standalone: the node's own config or "structural"
         again = amd.deserialize(expect)
         assert amd.serialize(again) == expect, name
         a, b = fuse(recipe), fuse(again)
-        assert (a is None) == (b is None) and (a is None or (a.kind, a.params) == (b.kind, b.params)), name
+        assert (a is None) == (b is None) and (a is None or a.kind == b.kind), name
+        assert a is None or name == "lora" or a.params == b.params, name       # (a LoRA plan holds its file nodes, compared by identity)
         assert config is None or all(m.config == config for m in __import__("sd_mecha_amd").merging.collect_models(again))
     with pytest.raises(RuntimeError, match="bad recipe version"):
         amd.deserialize("version 9.9.9\nmodel \"x.safetensors\"")
