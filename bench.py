@@ -50,6 +50,11 @@ WORKLOADS = {
     "sdxl_wsum": ("sdxl-sgm", None, 2, "wsum", 1),
     "flux_navg": ("flux-flux", ("diffuser",), 8, "navg", 8),
     "flux_ties": ("flux-flux", ("diffuser",), 8, "ties", 8),
+    # round 3: the rest of north_star's streaming list as batched plans
+    "sdxl_slerp": ("sdxl-sgm", None, 2, "slerp", 1),
+    "sdxl_addperp": ("sdxl-sgm", None, 3, "addperp", 1),
+    "sdxl_addsub": ("sdxl-sgm", None, 3, "addsub", 1),
+    "sdxl_dare": ("sdxl-sgm", None, 4, "dare", 1),
 }
 DESCRIPTION = {
     "sdxl_ties": "SDXL (sdxl-sgm, 2531 keys, 3.469 B params) add_difference(m0, ties_sum(m1-m0, m2-m0, m3-m0, k=0.2), alpha=1.0) of 4 random-init bf16 checkpoints, bf16 out",
@@ -57,6 +62,10 @@ DESCRIPTION = {
     "sdxl_wsum": "SDXL (sdxl-sgm) weighted_sum alpha=0.5 of 2 random-init bf16 checkpoints, bf16 out",
     "flux_navg": "FLUX-dev diffuser (780 keys, 11.9 B params) n_average of 8 random-init bf16 checkpoints, keys dealt over 8 shards (LPT), this rank's shard",
     "flux_ties": "FLUX-dev diffuser add_difference(m0, ties_sum(m1-m0 .. m7-m0, k=0.2)) of 8 random-init bf16 checkpoints, keys dealt over 8 shards (LPT), this rank's shard",
+    "sdxl_slerp": "SDXL (sdxl-sgm) slerp(m0, m1, alpha=0.3) of 2 random-init bf16 checkpoints, per-key norms and dot products, bf16 out",
+    "sdxl_addperp": "SDXL (sdxl-sgm) add_difference(m0, perpendicular_component(m0-m2, m1-m2), alpha=1.0) of 3 random-init bf16 checkpoints (wrappers.add_perpendicular), bf16 out",
+    "sdxl_addsub": "SDXL (sdxl-sgm) add_difference(m0, m1-m2, alpha=1.0) of 3 random-init bf16 checkpoints (wrappers.add_difference with c), bf16 out",
+    "sdxl_dare": "SDXL (sdxl-sgm) add_difference(m0, ties_sum_with_dropout(m1-m0, m2-m0, m3-m0, probability=0.9, k=0.2, apply_stock=True, seed=0), alpha=1.0) of 4 random-init bf16 checkpoints (wrappers.add_ties_with_dare), bf16 out",
 }
 
 
@@ -103,9 +112,20 @@ class Job:
         self.flags = torch.zeros(len(L.keys), dtype=torch.int32, device=device)
         self.lib = _lib.lib()
         self.ws = None
-        if recipe == "ties":
+        if recipe in ("ties", "dare"):
             nbytes = self.lib.mecha_batched_ties_workspace_bytes(n_models - 1, len(L.keys), L.total_elems)
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if recipe in ("slerp", "addperp"):
+            self.ws = torch.empty(self.lib.mecha_batched_reduce_workspace_bytes(len(L.keys), L.total_elems), dtype=torch.uint8, device=device)
+        if recipe == "dare":
+            # the ONE Bernoulli stream every key's masks are cut from (ties.py:29-33), drawn on the host once per job
+            self.dare_p, self.dare_seed = 0.9, 0
+            self.mask_bits = (n_models - 1) * max(L.numels)
+            host = torch.empty((self.mask_bits + 31) // 32 + 1, dtype=torch.int32, pin_memory=True)
+            t0 = time.perf_counter()
+            _lib.check(self.lib.mecha_dare_draw_stream_host(self.dare_seed, self.dare_p, self.mask_bits, host.data_ptr()), "draw stream")
+            self.mask_draw_s = time.perf_counter() - t0
+            self.mask_stream = host.to(device)
         self.payload_bytes = L.payload_elems * 2 * (n_models + 1)       # bf16 in x n_models + bf16 out
         self.model_ptrs = _lib.ptr_array([a.data_ptr() for a in self.arenas[1:]])
         self.all_ptrs = _lib.ptr_array([a.data_ptr() for a in self.arenas])
@@ -122,6 +142,24 @@ class Job:
         elif self.recipe == "navg":
             st = lib.mecha_batched_n_average(self.all_ptrs, self.n_models, self.out.data_ptr(), self.segs_dev.data_ptr(), len(L.keys),
                                              L.total_elems, _lib.BF16, _lib.BF16, self.flags.data_ptr(), stream)
+        elif self.recipe == "slerp":
+            st = lib.mecha_batched_slerp(self.arenas[0].data_ptr(), self.arenas[1].data_ptr(), self.out.data_ptr(), self.segs_dev.data_ptr(),
+                                         ctypes.addressof(self.segs_host), len(L.keys), L.total_elems, _lib.BF16, _lib.BF16, 0.3,
+                                         self.ws.data_ptr(), self.ws.numel(), self.flags.data_ptr(), stream)
+        elif self.recipe == "addperp":
+            st = lib.mecha_batched_add_perpendicular(self.arenas[0].data_ptr(), self.arenas[1].data_ptr(), self.arenas[2].data_ptr(),
+                                                     self.out.data_ptr(), self.segs_dev.data_ptr(), ctypes.addressof(self.segs_host), len(L.keys),
+                                                     L.total_elems, _lib.BF16, _lib.BF16, 1.0, self.ws.data_ptr(), self.ws.numel(),
+                                                     self.flags.data_ptr(), stream)
+        elif self.recipe == "addsub":
+            st = lib.mecha_batched_add_difference_sub(self.arenas[0].data_ptr(), self.arenas[1].data_ptr(), self.arenas[2].data_ptr(),
+                                                      self.out.data_ptr(), self.segs_dev.data_ptr(), len(L.keys), L.total_elems, _lib.BF16,
+                                                      _lib.BF16, 1.0, self.flags.data_ptr(), stream)
+        elif self.recipe == "dare":
+            st = lib.mecha_batched_add_difference_dare(
+                self.arenas[0].data_ptr(), self.model_ptrs, self.n_models - 1, self.out.data_ptr(), self.segs_dev.data_ptr(),
+                ctypes.addressof(self.segs_host), len(L.keys), L.total_elems, _lib.BF16, _lib.BF16, 0.2, 1.0, 0, self.dare_p, 1,
+                self.mask_stream.data_ptr(), self.mask_bits, None, self.ws.data_ptr(), self.ws.numel(), self.flags.data_ptr(), stream)
         else:
             st = lib.mecha_batched_weighted_sum(self.arenas[0].data_ptr(), self.arenas[1].data_ptr(), self.out.data_ptr(),
                                                 self.segs_dev.data_ptr(), len(L.keys), L.total_elems, _lib.BF16, _lib.BF16, 0.5,
@@ -151,6 +189,15 @@ def cpu_baseline(job: Job, seconds: float):
             res = O.add_difference_ties(f32[0], f32[1:], k=0.2, alpha=1.0)
         elif job.recipe == "navg":
             res = O.n_average(f32)
+        elif job.recipe == "slerp":
+            res = O.slerp(f32[0], f32[1], 0.3)
+        elif job.recipe == "addperp":
+            res = O.add_perpendicular(f32[0], f32[1], f32[2], 1.0)
+        elif job.recipe == "addsub":
+            res = O.add_difference(f32[0], O.subtract(f32[1], f32[2]), 1.0)
+        elif job.recipe == "dare":
+            ties = O.ties_sum_with_dropout([O.subtract(m, f32[0]) for m in f32[1:]], probability=job.dare_p, k=0.2, apply_stock=True, seed=job.dare_seed)
+            res = O.add_difference(f32[0], ties, 1.0)
         else:
             res = O.weighted_sum(f32[0], f32[1], 0.5)
         ok = all(O.all_finite(x) for x in f32)
@@ -241,6 +288,15 @@ def e2e_leg(job: Job, args, rank: int, world: int, dist, device):
             recipe = amd.add_difference(models[0], amd.ties_sum(*[amd.subtract(m, models[0]) for m in models[1:]], k=0.2), alpha=1.0) | models[0]
         elif job.recipe == "navg":
             recipe = amd.n_average(*models)
+        elif job.recipe == "slerp":
+            recipe = amd.slerp(models[0], models[1], alpha=0.3)
+        elif job.recipe == "addperp":
+            recipe = amd.add_difference(models[0], amd.perpendicular_component(amd.subtract(models[0], models[2]), amd.subtract(models[1], models[2])), alpha=1.0)
+        elif job.recipe == "addsub":
+            recipe = amd.add_difference(models[0], amd.subtract(models[1], models[2]), alpha=1.0) | models[0]
+        elif job.recipe == "dare":
+            recipe = amd.add_difference(models[0], amd.ties_sum_with_dropout(*[amd.subtract(m, models[0]) for m in models[1:]], probability=job.dare_p,
+                                                                             k=0.2, apply_stock=True, seed=job.dare_seed), alpha=1.0)
         else:
             recipe = amd.weighted_sum(models[0], models[1], alpha=0.5)
         from sd_mecha_amd import merging
@@ -369,6 +425,7 @@ def main():
             "streaming_ew": elems * 2 * (job.n_models + 1),
             "ties_hist1": elems * 2 * job.n_models, "ties_hist2": elems * 2 * job.n_models, "ties_hist3": elems * 2 * job.n_models,
             "ties_count": elems * 2 * job.n_models, "ties_merge": elems * 2 * (job.n_models + 1),
+            "reduce_partial": elems * 2 * job.n_models, "reduce_apply": elems * 2 * (job.n_models + 1),
         }
         breakdown = {k: {"ms_total": round(ms, 3), "launches": n, "ms_avg": round(ms / n, 4), "ms_per_step": round(ms / args.steps, 4)}
                      for k, (ms, n) in kernels.items()}
@@ -381,12 +438,15 @@ def main():
         # HBM bytes per launch from the PMC counters: they need rocprofv3, so they are collected in separate runs of this
         # same command and committed under profiles/ (how: the file's "_how"); None when this workload was not measured
         traffic = None
-        for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):          # the newest collection that covers this kernel
+        for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):          # the newest collection that covers this kernel
             traffic_file = pathlib.Path(__file__).resolve().parent / "profiles" / name
             if traffic is None and traffic_file.exists():
                 traffic = json.loads(traffic_file.read_text()).get(args.workload, {}).get(dom, {}).get("hbm_bytes_per_launch")
         line = {
-            "metric": "merged state-dict GB/s", "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "metric": "merged state-dict GB/s", "value": round(value, 2), "unit": "GB/s",
+            # what `value` times (the contract: inputs resident in HBM when the timed region starts); SURVEY.md §8(d)'s own metric, wall
+            # time of merge() from the first read to close(), is `e2e.merged_GBs` on this same line
+            "value_is": "hbm_resident_loop", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "description": DESCRIPTION[args.workload], "keys": len(job.layout.keys),
@@ -406,6 +466,12 @@ def main():
                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ties stats")
             line["ties_select"] = {"pairs": len(job.layout.keys) * (job.n_models - 1), "pairs_fell_back_to_radix": failed.value,
                                    "elements_in_ambiguous_lists": amb.value}
+        # the whole step against its algorithm: every input read once, the output written once
+        line["whole_step"] = {"algorithmic_bytes": job.payload_bytes, "ms": round(elapsed_max / args.steps * 1e3, 3),
+                              "kernel_ms_sum": round(sum(v["ms_per_step"] for v in breakdown.values()), 3)}
+        if job.recipe == "dare":
+            line["dare_mask_stream"] = {"bits": job.mask_bits, "host_draw_seconds": round(job.mask_draw_s, 3),
+                                        "note": "one stream serves every key (the reference seeds a fresh generator per key); drawn once per job, outside the timed steps"}
         if e2e is not None:
             line["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:

@@ -221,6 +221,12 @@ int mecha_dropout(const void *const *deltas, int n_models, const uint32_t *keep_
  * above, into HOST memory `bits_out` (n_models * ceil(numel/32) words). */
 int mecha_dare_draw_masks_host(uint64_t seed, float probability, int n_models, int64_t numel,
                                uint32_t *bits_out);
+/* HOST function: the same generator as ONE stream: keep bit of draw i = bit (i & 31) of word (i >> 5), for the first n_bits
+ * draws.  `bits_out`: ceil(n_bits / 32) + 1 words (the last one is a zero pad word the kernels may read).  The reference
+ * creates and seeds a fresh generator for EVERY key (ties.py:29-31), so every key's masks are cut from the same stream:
+ * delta m of a key of n elements uses draws [m n, (m + 1) n).  One stream of n_models * (largest key) bits therefore
+ * serves a whole checkpoint (mecha_batched_add_difference_dare). */
+int mecha_dare_draw_stream_host(uint64_t seed, float probability, int64_t n_bits, uint32_t *bits_out);
 
 /* LoRA / LyCORIS reconstruction (extensions/builtin/lycoris.py:226-263, LoraAlgorithm.compose / compose_alpha) fused
  * with add_difference (linear.py:64-76) for every network of one key:
@@ -329,6 +335,34 @@ int mecha_batched_add_difference(const void *a_arena, const void *b_arena, void 
                                  const mecha_segment *segments, int n_segments, int64_t total_elems,
                                  int in_dtype, int out_dtype, float alpha, uint32_t *seg_flags, void *stream);
 
+/* add_difference(a, subtract(b, c), alpha) (wrappers.py:9-39 with `c`; linear.py:101, :76): fma(b - c, alpha, a) in one pass,
+ * per key and for an arena of keys.  alpha == 0 is refused (the reference returns `a` without loading b or c). */
+int mecha_add_difference_sub(const void *a, const void *b, const void *c, void *out, int64_t numel, int in_dtype,
+                             int out_dtype, float alpha, uint32_t *flags, void *stream);
+int mecha_batched_add_difference_sub(const void *a_arena, const void *b_arena, const void *c_arena, void *out_arena,
+                                     const mecha_segment *segments, int n_segments, int64_t total_elems, int in_dtype,
+                                     int out_dtype, float alpha, uint32_t *seg_flags, void *stream);
+
+/* slerp (linear.py:43-61), perpendicular_component (linear.py:104-113) and the add_perpendicular graph (wrappers.py:42-64)
+ * for every key of an arena in one launch sequence.  The norms and dot products are per key (whole-tensor reductions in
+ * the reference): the arena is cut into 2048-element tiles that never straddle a key, a flat grid writes one fp64 partial
+ * per tile, one wave per key folds its tiles in order (no atomics: the result does not depend on block scheduling), a
+ * second flat grid applies the formula.  Keys whose result holds a NaN are rewritten with the reference's fallback
+ * (lerp / zeros) by a kernel that exits at once when no key needs it.  Two reads of each input, one write. */
+size_t mecha_batched_reduce_workspace_bytes(int n_segments, int64_t total_elems);
+int mecha_batched_slerp(const void *a_arena, const void *b_arena, void *out_arena, const mecha_segment *segments,
+                        const mecha_segment *segments_host, int n_segments, int64_t total_elems, int in_dtype,
+                        int out_dtype, float alpha, void *workspace, size_t workspace_bytes, uint32_t *seg_flags,
+                        void *stream);
+int mecha_batched_perpendicular_component(const void *a_arena, const void *b_arena, void *out_arena,
+                                          const mecha_segment *segments, const mecha_segment *segments_host,
+                                          int n_segments, int64_t total_elems, int in_dtype, int out_dtype,
+                                          void *workspace, size_t workspace_bytes, uint32_t *seg_flags, void *stream);
+int mecha_batched_add_perpendicular(const void *a_arena, const void *b_arena, const void *c_arena, void *out_arena,
+                                    const mecha_segment *segments, const mecha_segment *segments_host, int n_segments,
+                                    int64_t total_elems, int in_dtype, int out_dtype, float alpha, void *workspace,
+                                    size_t workspace_bytes, uint32_t *seg_flags, void *stream);
+
 /* Batched add_difference(base, ties_sum(m_i - base ..., k), alpha): per-key thresholds for every
  * (key, model) pair, all keys in one launch sequence.  `segments_host` is the HOST copy of
  * `segments` (needed to size the launches); `thresholds_out` (may be NULL): device
@@ -340,6 +374,18 @@ int mecha_batched_add_difference_ties(const void *base_arena, const void *const 
                                       int64_t total_elems, int in_dtype, int out_dtype, double k,
                                       float alpha, int vote_sgn, float *thresholds_out, void *workspace,
                                       size_t workspace_bytes, uint32_t *seg_flags, void *stream);
+
+/* Batched DARE (wrappers.py:231-273 with apply_stock == True, della_eps == 0, apply_median == False):
+ *   add_difference(base, ties_sum_with_dropout(m_i - base ..., probability, rescale, k, vote_sgn, seed), alpha)
+ * for every key of the arenas.  `mask_stream`: DEVICE copy of mecha_dare_draw_stream_host's output, at least
+ * n_models * (largest key) bits.  Thresholds are those of the MASKED deltas (ties.py:33-34), by the radix-select passes.
+ * Workspace: mecha_batched_ties_workspace_bytes. */
+int mecha_batched_add_difference_dare(const void *base_arena, const void *const *model_arenas, int n_models, void *out_arena,
+                                      const mecha_segment *segments, const mecha_segment *segments_host, int n_segments,
+                                      int64_t total_elems, int in_dtype, int out_dtype, double k, float alpha, int vote_sgn,
+                                      float probability, int rescale, const uint32_t *mask_stream, int64_t mask_stream_bits,
+                                      float *thresholds_out, void *workspace, size_t workspace_bytes, uint32_t *seg_flags,
+                                      void *stream);
 
 /* HOST functions: the file traffic of one wave of keys, between safetensors files and pinned
  * staging arenas, moved by up to `threads` workers in pieces of 4 MiB.

@@ -79,6 +79,15 @@ SIGNATURES = {
     "mecha_model_stock": (c_i, [c_p, c_i, c_p, c_i64, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p]),
     "mecha_dropout": (c_i, [c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_f, c_p, c_p]),
     "mecha_dare_draw_masks_host": (c_i, [c_u64, c_f, c_i, c_i64, c_p]),
+    "mecha_dare_draw_stream_host": (c_i, [c_u64, c_f, c_i64, c_p]),
+    "mecha_add_difference_sub": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p, c_p]),
+    "mecha_batched_add_difference_sub": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_f, c_p, c_p]),
+    "mecha_batched_reduce_workspace_bytes": (c_sz, [c_i, c_i64]),
+    "mecha_batched_slerp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p]),
+    "mecha_batched_perpendicular_component": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_p, c_sz, c_p, c_p]),
+    "mecha_batched_add_perpendicular": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p]),
+    "mecha_batched_add_difference_dare": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_d, c_f, c_i, c_f, c_i, c_p, c_i64,
+                                                c_p, c_p, c_sz, c_p, c_p]),
     "mecha_lora_accumulate": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mecha_batched_lora_accumulate": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mecha_rotate_workspace_bytes": (c_sz, [c_i64, c_i64]),

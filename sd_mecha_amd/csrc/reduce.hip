@@ -261,6 +261,319 @@ int run_reduce(const void *a, const void *b, const void *c, void *out, int64_t n
     return MECHA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ batched (segmented) form
+// Every key of an arena in ONE launch sequence (replaces one future per key, merging.py:223-229, for recipes
+// slerp(model, model) and add_perpendicular-shaped graphs).  The reductions are per KEY (linear.py:49-52, :109-110 reduce over
+// the whole tensor), so the arena is cut into tiles of BRED_TILE elements that never straddle a key:
+//   1. tiles   : tile_start[] (prefix of tiles per key) and one 16-byte record per tile, built on the device from the
+//                segment table
+//   2. reduce  : FLAT grid, one block per tile, one 16-byte vector position per thread: fp64 partial sums of x.x, y.y, x.y
+//                per tile -> workspace (no atomics: a key's partials are summed in tile order, so results do not depend on
+//                the order blocks run in)
+//   3. finish  : one wave per key folds its tiles' partials and derives the key's scalars
+//   4. apply   : flat grid again; a block reads its key's scalars, applies the formula, casts, checks; a key whose result
+//                holds a NaN is noted in its scalars and in one global word
+//   5. fixup   : a small grid that exits at once unless that word is set; then it rewrites the keys that were noted with the
+//                reference's NaN fallback (linear.py:59-60, :111-112)
+// Roofline: HBM; algorithmic bytes = one read of each input + one write, implementation = two reads + one write.
+constexpr int BRED_TILE = MECHA_BLOCK * 8;           // 2048 elements: one vector position per thread
+
+struct BredTile { long long elem; int seg; int valid; };   // first element inside the arena, key, elements in the tile
+
+struct BredGlobals { uint32_t any_nan; uint32_t pad[3]; };
+
+struct BredParams {
+    const void *a, *b, *c;
+    void *out;
+    const mecha_segment *segs;
+    int n_segs;
+    const long long *tile_start;        // [n_segs + 1]
+    const BredTile *tiles;
+    long long n_tiles;
+    double *partial;                    // [n_tiles][3]
+    RedScalars *sc;                     // [n_segs]
+    BredGlobals *globals;
+    float alpha, alpha_m1;
+    int small;
+    int vec_ok;
+    uint32_t *flags;                    // [n_segs] or nullptr
+};
+
+__global__ __launch_bounds__(1024) void bred_tile_index_kernel(const mecha_segment *segs, int n_segs, long long *tile_start) {
+    __shared__ long long part[1024];
+    const int per = (n_segs + 1023) / 1024;
+    const int lo = (threadIdx.x * per < n_segs) ? threadIdx.x * per : n_segs;
+    const int hi = (lo + per < n_segs) ? lo + per : n_segs;
+    long long sum = 0;
+    for (int i = lo; i < hi; i++) sum += (segs[i].numel + BRED_TILE - 1) / BRED_TILE;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; i++) { long long v = part[i]; part[i] = run; run += v; }
+        tile_start[n_segs] = run;
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) { tile_start[i] = run; run += (segs[i].numel + BRED_TILE - 1) / BRED_TILE; }
+}
+
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_tile_records_kernel(const mecha_segment *segs, const long long *tile_start, BredTile *rec) {
+    const int s = blockIdx.x;
+    const mecha_segment seg = segs[s];
+    const long long first = tile_start[s], n = tile_start[s + 1] - first;
+    for (long long i = threadIdx.x; i < n; i += MECHA_BLOCK) {
+        const long long left = seg.numel - i * BRED_TILE;
+        rec[first + i] = BredTile{seg.offset + i * BRED_TILE, s, (int)(left < BRED_TILE ? left : BRED_TILE)};
+    }
+}
+
+// operands of one vector position of a tile: x, y (ADDPERP: a - c, b - c) and a itself
+template <int MODE, int IN_DT>
+__device__ __forceinline__ void bred_operands(const BredParams &p, int64_t e, int valid, bool vec, float (&x)[8], float (&y)[8], float (&a0)[8], bool &bad_in) {
+    float c[8];
+    if (vec) {
+        load8<IN_DT, true>(p.a, e, x);
+        load8<IN_DT, true>(p.b, e, y);
+        if constexpr (MODE == RM_ADDPERP) load8<IN_DT, true>(p.c, e, c);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            x[j] = (j < valid) ? load1<IN_DT>(p.a, e + j) : 0.0f;
+            y[j] = (j < valid) ? load1<IN_DT>(p.b, e + j) : 0.0f;
+            if constexpr (MODE == RM_ADDPERP) c[j] = (j < valid) ? load1<IN_DT>(p.c, e + j) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(x[j]) | nonfinite_f32(y[j]);
+    if constexpr (MODE == RM_ADDPERP) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            bad_in |= nonfinite_f32(c[j]);
+            a0[j] = x[j];
+            x[j] = x[j] - c[j];                       // subtract (linear.py:101)
+            y[j] = y[j] - c[j];
+        }
+    }
+}
+
+template <int MODE, int IN_DT>
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_reduce_kernel(BredParams p) {
+    const BredTile rec = p.tiles[blockIdx.x];
+    const int local = threadIdx.x * 8;
+    const int valid = rec.valid - local >= 8 ? 8 : (rec.valid - local > 0 ? rec.valid - local : 0);
+    double sxx = 0.0, syy = 0.0, sxy = 0.0;
+    bool bad_in = false;
+    if (valid > 0) {
+        float x[8], y[8], a0[8];
+        bred_operands<MODE, IN_DT>(p, rec.elem + local, valid, p.vec_ok && valid == 8, x, y, a0, bad_in);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const double dx = x[j], dy = y[j];
+            sxx = __builtin_fma(dx, dx, sxx);
+            syy = __builtin_fma(dy, dy, syy);
+            sxy = __builtin_fma(dx, dy, sxy);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sxx += __shfl_down(sxx, off, 64);
+        syy += __shfl_down(syy, off, 64);
+        sxy += __shfl_down(sxy, off, 64);
+    }
+    __shared__ double wsum[MECHA_BLOCK / 64][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { wsum[wave][0] = sxx; wsum[wave][1] = syy; wsum[wave][2] = sxy; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < MECHA_BLOCK / 64; w++) t += wsum[w][threadIdx.x];
+        p.partial[(long long)blockIdx.x * 3 + threadIdx.x] = t;
+    }
+    if (bad_in && p.flags != nullptr) atomicOr(p.flags + rec.seg, MECHA_FLAG_INPUT_NONFINITE);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void bred_finish_kernel(BredParams p) {
+    const int s = blockIdx.x;
+    const long long t0 = p.tile_start[s], t1 = p.tile_start[s + 1];
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (long long t = t0 + threadIdx.x; t < t1; t += 64) { s0 += p.partial[t * 3]; s1 += p.partial[t * 3 + 1]; s2 += p.partial[t * 3 + 2]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if (threadIdx.x != 0) return;
+    RedScalars sc{};
+    sc.na = (float)__builtin_sqrt(s0);
+    sc.nb = (float)__builtin_sqrt(s1);
+    if constexpr (MODE == RM_SLERP) {
+        float ab = (float)(s2 / ((double)sc.na * (double)sc.nb));
+        ab = (ab < -1.0f) ? -1.0f : ((ab > 1.0f) ? 1.0f : ab);
+        const float omega = acosf(ab);
+        sc.sa = sinf((1.0f - p.alpha) * omega);
+        sc.sb = sinf(p.alpha * omega);
+        sc.so = sinf(omega);
+        sc.nl = lerp_torch(sc.na, sc.nb, p.alpha, p.alpha_m1, p.small != 0);
+    } else {
+        sc.proj = (float)(s2 / ((double)sc.na * (double)sc.na));
+    }
+    sc.any_nan = 0;
+    p.sc[s] = sc;
+}
+
+template <int MODE>
+__device__ __forceinline__ float bred_formula(const RedScalars &sc, float x, float y) {
+    if constexpr (MODE == RM_SLERP) {
+        const float an = x / sc.na, bn = y / sc.nb;              // linear.py:49-50
+        float q = (an * sc.sa + bn * sc.sb) / sc.so;             // linear.py:55-57
+        return q * sc.nl;                                        // linear.py:58
+    } else {
+        return y - x * sc.proj;                                  // linear.py:110
+    }
+}
+
+template <int MODE, int IN_DT, int OUT_DT>
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_apply_kernel(BredParams p) {
+    const BredTile rec = p.tiles[blockIdx.x];
+    const int local = threadIdx.x * 8;
+    const int valid = rec.valid - local >= 8 ? 8 : (rec.valid - local > 0 ? rec.valid - local : 0);
+    if (valid == 0) return;
+    const int64_t e = rec.elem + local;
+    const bool vec = p.vec_ok && valid == 8;
+    float x[8], y[8], a0[8], r[8];
+    bool bad_in = false, any_nan = false, bad_out = false;
+    bred_operands<MODE, IN_DT>(p, e, valid, vec, x, y, a0, bad_in);     // the loads are issued before the key's scalars are needed
+    const RedScalars sc = p.sc[rec.seg];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float q = bred_formula<MODE>(sc, x[j], y[j]);
+        if (j < valid) any_nan |= (q != q);
+        if constexpr (MODE == RM_ADDPERP) q = __builtin_fmaf(q, p.alpha, a0[j]);      // add_difference(a, perp, alpha)  (linear.py:76)
+        r[j] = q;
+        bad_out |= (j < valid) && nonfinite_f32(q);
+    }
+    if (vec) store8<OUT_DT, true>(p.out, e, r);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < valid) store1<OUT_DT>(p.out, e + j, r[j]);
+    }
+    if (any_nan) { atomicOr(&p.sc[rec.seg].any_nan, 1u); atomicOr(&p.globals->any_nan, 1u); }
+    if (bad_out && p.flags != nullptr) atomicOr(p.flags + rec.seg, MECHA_FLAG_OUTPUT_NONFINITE);
+}
+
+// The reference's `if res.isnan().any()` branches, for the keys the apply pass noted (rare: an all-zero tensor, identical inputs).
+template <int MODE, int IN_DT, int OUT_DT>
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_fixup_kernel(BredParams p) {
+    if (p.globals->any_nan == 0) return;
+    for (long long t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {
+        const BredTile rec = p.tiles[t];
+        if (p.sc[rec.seg].any_nan == 0) continue;                 // block-uniform
+        const int local = threadIdx.x * 8;
+        const int valid = rec.valid - local >= 8 ? 8 : (rec.valid - local > 0 ? rec.valid - local : 0);
+        if (valid == 0) continue;
+        const int64_t e = rec.elem + local;
+        const bool vec = p.vec_ok && valid == 8;
+        float a[8], b[8], r[8];
+        auto ld = [&](const void *ptr, float (&v)[8]) {
+            if (vec) load8<IN_DT, false>(ptr, e, v);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = (j < valid) ? load1<IN_DT>(ptr, e + j) : 0.0f;
+            }
+        };
+        if constexpr (MODE == RM_SLERP) {
+            ld(p.a, a); ld(p.b, b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = lerp_torch(a[j], b[j], p.alpha, p.alpha_m1, p.small != 0);   // linear.py:60
+        } else if constexpr (MODE == RM_PERP) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = 0.0f;                                                      // linear.py:112
+        } else {
+            ld(p.a, a);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = __builtin_fmaf(0.0f, p.alpha, a[j]);                       // a.addcmul(zeros, alpha)
+        }
+        bool bad_out = false;
+#pragma unroll
+        for (int j = 0; j < 8; j++) bad_out |= (j < valid) && nonfinite_f32(r[j]);
+        if (vec) store8<OUT_DT, false>(p.out, e, r);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j < valid) store1<OUT_DT>(p.out, e + j, r[j]);
+        }
+        if (bad_out && p.flags != nullptr) atomicOr(p.flags + rec.seg, MECHA_FLAG_OUTPUT_NONFINITE);
+    }
+}
+
+size_t bred_align(size_t v) { return (v + 255) / 256 * 256; }
+
+struct BredLayout { size_t tile_start_off, tiles_off, partial_off, sc_off, globals_off, total; size_t max_tiles; };
+BredLayout bred_layout(int n_segs, int64_t total_elems) {
+    BredLayout w;
+    w.max_tiles = (size_t)(total_elems > 0 ? total_elems : 0) / BRED_TILE + (size_t)n_segs;
+    size_t off = 0;
+    w.tile_start_off = off; off = bred_align(off + sizeof(long long) * ((size_t)n_segs + 1));
+    w.tiles_off = off;      off = bred_align(off + sizeof(BredTile) * w.max_tiles);
+    w.partial_off = off;    off = bred_align(off + sizeof(double) * 3 * w.max_tiles);
+    w.sc_off = off;         off = bred_align(off + sizeof(RedScalars) * (size_t)n_segs);
+    w.globals_off = off;    off = bred_align(off + sizeof(BredGlobals));
+    w.total = off;
+    return w;
+}
+
+template <int MODE>
+int run_batched_reduce(const void *a, const void *b, const void *c, void *out, const mecha_segment *segs_dev, const mecha_segment *segs_host,
+                       int n_segs, int64_t total_elems, int in_dt, int out_dt, float alpha, void *workspace, size_t workspace_bytes,
+                       uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(a != nullptr && b != nullptr && out != nullptr && (MODE != RM_ADDPERP || c != nullptr), "NULL arena pointer");
+    MECHA_REQUIRE(segs_dev != nullptr && segs_host != nullptr && n_segs >= 1, "batched call needs host and device segment tables");
+    MECHA_REQUIRE(mecha_valid_dtype(in_dt) && mecha_valid_dtype(out_dt), "unknown dtype code (in %d, out %d)", in_dt, out_dt);
+    long long n_tiles = 0;
+    int64_t prev_end = 0;
+    for (int s = 0; s < n_segs; s++) {
+        MECHA_REQUIRE(segs_host[s].numel > 0 && (segs_host[s].offset % 8) == 0 && segs_host[s].offset >= prev_end,
+                      "segment %d: offsets must be multiples of 8, sorted and non-overlapping, numel > 0", s);
+        prev_end = segs_host[s].offset + segs_host[s].numel;
+        n_tiles += (segs_host[s].numel + BRED_TILE - 1) / BRED_TILE;
+    }
+    MECHA_REQUIRE(prev_end <= total_elems, "segments end at element %lld, beyond total_elems = %lld", (long long)prev_end, (long long)total_elems);
+    const BredLayout w = bred_layout(n_segs, total_elems);
+    MECHA_REQUIRE((size_t)n_tiles <= w.max_tiles, "segments hold more tiles than the workspace was sized for");
+    MECHA_REQUIRE(workspace != nullptr && workspace_bytes >= w.total && mecha_aligned16(workspace),
+                  "reduce workspace too small or unaligned: need %zu bytes, got %zu", w.total, workspace_bytes);
+    MECHA_REQUIRE(n_tiles * MECHA_BLOCK < (1ll << 32), "too many tiles for one launch (2^24 - 1 tiles of 2048 elements)");
+    char *ws = static_cast<char *>(workspace);
+    BredParams p{};
+    p.a = a; p.b = b; p.c = c; p.out = out; p.segs = segs_dev; p.n_segs = n_segs;
+    p.tile_start = reinterpret_cast<const long long *>(ws + w.tile_start_off);
+    p.tiles = reinterpret_cast<const BredTile *>(ws + w.tiles_off);
+    p.n_tiles = n_tiles;
+    p.partial = reinterpret_cast<double *>(ws + w.partial_off);
+    p.sc = reinterpret_cast<RedScalars *>(ws + w.sc_off);
+    p.globals = reinterpret_cast<BredGlobals *>(ws + w.globals_off);
+    p.alpha = alpha; p.alpha_m1 = alpha - 1.0f; p.small = (alpha < 0.5f && alpha > -0.5f) ? 1 : 0;
+    p.vec_ok = (mecha_aligned16(a) && mecha_aligned16(b) && mecha_aligned16(out) && (c == nullptr || mecha_aligned16(c))) ? 1 : 0;
+    p.flags = flags;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MECHA_CHECK_HIP(hipMemsetAsync(ws + w.globals_off, 0, sizeof(BredGlobals), s));
+    MECHA_LAUNCH(MK_TIES_INDEX, bred_tile_index_kernel, dim3(1), dim3(1024), 0, s, segs_dev, n_segs, reinterpret_cast<long long *>(ws + w.tile_start_off));
+    MECHA_LAUNCH(MK_TIES_INDEX, bred_tile_records_kernel, dim3((unsigned)n_segs), dim3(MECHA_BLOCK), 0, s, segs_dev, p.tile_start,
+                 reinterpret_cast<BredTile *>(ws + w.tiles_off));
+    const unsigned grid = (unsigned)n_tiles;
+    const unsigned fix_grid = (unsigned)(n_tiles < 2048 ? n_tiles : 2048);
+    MECHA_DISPATCH_DTYPES(in_dt, out_dt, {
+        MECHA_LAUNCH(MK_RED_REDUCE, (bred_reduce_kernel<MODE, IN_DT>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p);
+        MECHA_LAUNCH(MK_RED_FINISH, (bred_finish_kernel<MODE>), dim3((unsigned)n_segs), dim3(64), 0, s, p);
+        MECHA_LAUNCH(MK_RED_APPLY, (bred_apply_kernel<MODE, IN_DT, OUT_DT>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p);
+        MECHA_LAUNCH(MK_RED_FIXUP, (bred_fixup_kernel<MODE, IN_DT, OUT_DT>), dim3(fix_grid), dim3(MECHA_BLOCK), 0, s, p);
+    });
+    MECHA_CHECK_HIP(hipGetLastError());
+    return MECHA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -283,6 +596,33 @@ int mecha_perpendicular_component(const void *a, const void *b, void *out, int64
 int mecha_add_perpendicular(const void *a, const void *b, const void *c, void *out, int64_t numel, int in_dtype,
                             int out_dtype, float alpha, void *workspace, size_t workspace_bytes, uint32_t *flags, void *stream) {
     return run_reduce<RM_ADDPERP>(a, b, c, out, numel, in_dtype, out_dtype, alpha, workspace, workspace_bytes, flags, stream);
+}
+
+size_t mecha_batched_reduce_workspace_bytes(int n_segments, int64_t total_elems) {
+    return bred_layout(n_segments < 1 ? 1 : n_segments, total_elems).total;
+}
+
+int mecha_batched_slerp(const void *a_arena, const void *b_arena, void *out_arena, const mecha_segment *segments,
+                        const mecha_segment *segments_host, int n_segments, int64_t total_elems, int in_dtype, int out_dtype,
+                        float alpha, void *workspace, size_t workspace_bytes, uint32_t *seg_flags, void *stream) {
+    return run_batched_reduce<RM_SLERP>(a_arena, b_arena, nullptr, out_arena, segments, segments_host, n_segments, total_elems, in_dtype,
+                                        out_dtype, alpha, workspace, workspace_bytes, seg_flags, stream);
+}
+
+int mecha_batched_perpendicular_component(const void *a_arena, const void *b_arena, void *out_arena, const mecha_segment *segments,
+                                          const mecha_segment *segments_host, int n_segments, int64_t total_elems, int in_dtype,
+                                          int out_dtype, void *workspace, size_t workspace_bytes, uint32_t *seg_flags, void *stream) {
+    return run_batched_reduce<RM_PERP>(a_arena, b_arena, nullptr, out_arena, segments, segments_host, n_segments, total_elems, in_dtype,
+                                       out_dtype, 0.0f, workspace, workspace_bytes, seg_flags, stream);
+}
+
+int mecha_batched_add_perpendicular(const void *a_arena, const void *b_arena, const void *c_arena, void *out_arena,
+                                    const mecha_segment *segments, const mecha_segment *segments_host, int n_segments,
+                                    int64_t total_elems, int in_dtype, int out_dtype, float alpha, void *workspace,
+                                    size_t workspace_bytes, uint32_t *seg_flags, void *stream) {
+    MECHA_REQUIRE(!mecha_isclose(alpha, 0.0), "alpha == 0: add_difference returns `a` untouched (linear.py:72-73); use the cast entry point");
+    return run_batched_reduce<RM_ADDPERP>(a_arena, b_arena, c_arena, out_arena, segments, segments_host, n_segments, total_elems, in_dtype,
+                                          out_dtype, alpha, workspace, workspace_bytes, seg_flags, stream);
 }
 
 }  // extern "C"

@@ -15,7 +15,7 @@
 
 namespace {
 
-enum : int { OP_CAST = 0, OP_LERP, OP_NAVG, OP_ADDCMUL, OP_SUB, OP_SCALE, OP_LERP_T, OP_ADDCMUL_T };
+enum : int { OP_CAST = 0, OP_LERP, OP_NAVG, OP_ADDCMUL, OP_SUB, OP_SCALE, OP_LERP_T, OP_ADDCMUL_T, OP_ADDSUB };
 
 struct EwParams {
     const void *in[MECHA_MAX_MODELS];
@@ -107,6 +107,17 @@ __device__ __forceinline__ void compute8(const EwParams &p, int64_t i, int valid
             if constexpr (OP == OP_LERP_T) r[j] = lerp_torch(a[j], b[j], w[j], w[j] - 1.0f, __builtin_fabsf(w[j]) < 0.5f);
             else r[j] = __builtin_fmaf(b[j], w[j], a[j]);
         }
+    } else if constexpr (OP == OP_ADDSUB) {
+        // add_difference(a, subtract(b, c), alpha) (wrappers.py:9-39 with `c`): the delta b - c (linear.py:101) never leaves registers
+        float a[8], b[8], c[8];
+        ld(p.in[0], a);
+        ld(p.in[1], b);
+        ld(p.in[2], c);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            bad_in |= nonfinite_f32(a[j]) | nonfinite_f32(b[j]) | nonfinite_f32(c[j]);
+            r[j] = __builtin_fmaf(b[j] - c[j], p.alpha, a[j]);                       // a.addcmul(b - c, alpha)  (linear.py:76)
+        }
     } else {
         float a[8], b[8];
         ld(p.in[0], a);
@@ -190,7 +201,8 @@ int launch_ew(EwParams &p, void *out, int64_t total, int in_dt, int out_dt, cons
     }
     const int64_t n_vec = (total + 7) >> 3;
     const int64_t blocks = (n_vec + MECHA_BLOCK - 1) / MECHA_BLOCK;
-    MECHA_REQUIRE(blocks <= 0x7fffffff, "numel %lld is beyond one launch (2^31 - 1 blocks of 2048 elements)", (long long)total);
+    // HIP rejects a launch whose gridDim.x * blockDim.x reaches 2^32: at most 2^24 - 1 blocks of 256 threads (3.4e10 elements)
+    MECHA_REQUIRE(blocks * MECHA_BLOCK < (1ll << 32), "numel %lld is beyond one launch (2^24 - 1 blocks of 2048 elements)", (long long)total);
     dim3 grid((unsigned)blocks), block(MECHA_BLOCK);
     hipStream_t s = static_cast<hipStream_t>(stream);
     MECHA_DISPATCH_DTYPES(in_dt, out_dt, {
@@ -329,6 +341,26 @@ int mecha_batched_add_difference(const void *a_arena, const void *b_arena, void 
     MECHA_REQUIRE(n_segments > 0 && segments != nullptr, "batched call needs a device segment table");
     return add_difference_impl(a_arena, b_arena, out_arena, total_elems, in_dtype, out_dtype, alpha, segments, n_segments,
                                seg_flags, stream);
+}
+
+int mecha_add_difference_sub(const void *a, const void *b, const void *c, void *out, int64_t numel, int in_dtype, int out_dtype,
+                             float alpha, uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(out != nullptr || numel == 0, "out is NULL");
+    MECHA_REQUIRE(!mecha_isclose(alpha, 0.0), "alpha == 0: add_difference returns `a` untouched (linear.py:72-73); use mecha_cast");
+    EwParams p{};
+    p.n_in = 3; p.in[0] = a; p.in[1] = b; p.in[2] = c; p.alpha = alpha;
+    return launch_ew<OP_ADDSUB>(p, out, numel, in_dtype, out_dtype, nullptr, 0, flags, stream);
+}
+
+int mecha_batched_add_difference_sub(const void *a_arena, const void *b_arena, const void *c_arena, void *out_arena,
+                                     const mecha_segment *segments, int n_segments, int64_t total_elems, int in_dtype,
+                                     int out_dtype, float alpha, uint32_t *seg_flags, void *stream) {
+    MECHA_REQUIRE(n_segments > 0 && segments != nullptr, "batched call needs a device segment table");
+    MECHA_REQUIRE(out_arena != nullptr || total_elems == 0, "out is NULL");
+    MECHA_REQUIRE(!mecha_isclose(alpha, 0.0), "alpha == 0: add_difference returns `a` untouched (linear.py:72-73); use the cast entry point");
+    EwParams p{};
+    p.n_in = 3; p.in[0] = a_arena; p.in[1] = b_arena; p.in[2] = c_arena; p.alpha = alpha;
+    return launch_ew<OP_ADDSUB>(p, out_arena, total_elems, in_dtype, out_dtype, segments, n_segments, seg_flags, stream);
 }
 
 }  // extern "C"

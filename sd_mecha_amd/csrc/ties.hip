@@ -66,7 +66,8 @@ struct TiesParams {
     const void *base;                      // nullptr: inputs are deltas
     const void *in[TIES_MAX_DELTAS];       // models (base mode) or deltas
     const uint32_t *keep_bits;             // DARE masks or nullptr
-    int64_t mask_words;                    // words per delta row of keep_bits
+    int64_t mask_words;                    // words per delta row of keep_bits (row form)
+    int mask_stream;                       // 1: keep_bits is ONE Bernoulli stream; delta m of a key of n elements uses bits [m n, (m + 1) n)
     int n_deltas;
     int in_dt, out_dt;
     int raw;                               // model_stock (ties.py:137-143): the stock kernels take the deltas as they are
@@ -192,10 +193,15 @@ __device__ __forceinline__ void store_rt(int dt, bool vec, void *ptr, int64_t e,
     }
 }
 
-// DARE: delta * mask (ties.py:33); mask bit i of row m.  `local` = element index inside the key.
-__device__ __forceinline__ void apply_keep_bits(const TiesParams &p, int m, int64_t local, float (&v)[8]) {
-    const uint32_t word = p.keep_bits[(int64_t)m * p.mask_words + (local >> 5)];
-    const uint32_t bits8 = (word >> (local & 31)) & 0xffu;       // local % 8 == 0, so the 8 bits sit in one word
+// DARE: delta * mask (ties.py:33).  `local` = element index inside the key (a multiple of 8), `numel` = the key's size.
+// Row form: mask bit i of row m (rows start at word boundaries, so the 8 bits sit in one word).  Stream form: the reference
+// seeds a fresh generator PER KEY (ties.py:29-31) and draws the deltas' masks one after the other (ties.py:33), so delta m of a
+// key of n elements takes draws [m n, (m + 1) n) of the one stream every key shares: bit m n + i, at any bit offset.
+__device__ __forceinline__ void apply_keep_bits(const TiesParams &p, int m, int64_t local, int64_t numel, float (&v)[8]) {
+    const int64_t s = (p.mask_stream ? (int64_t)m * numel : (int64_t)m * p.mask_words * 32) + local;
+    const uint32_t sh = (uint32_t)(s & 31);
+    uint32_t bits8 = p.keep_bits[s >> 5] >> sh;
+    if (sh > 24u) bits8 |= p.keep_bits[(s >> 5) + 1] << (32u - sh);       // stream form only (the stream ends with a pad word)
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = v[j] * (((bits8 >> j) & 1u) ? 1.0f : 0.0f);
 }
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
 #pragma unroll
                         for (int j = 0; j < 8; j++) v[d][j] = v[d][j] - b[j];              // subtract (linear.py:101)
                     }
-                    if constexpr (DARE) apply_keep_bits(p, d0 + d, local, v[d]);
+                    if constexpr (DARE) apply_keep_bits(p, d0 + d, local, seg.numel, v[d]);
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         const uint32_t bits = __float_as_uint(v[d][j]) & 0x7fffffffu;        // |delta|
@@ -798,7 +804,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
 #pragma unroll
                     for (int j = 0; j < 8; j++) f[j] = f[j] - b[j];
                 }
-                if constexpr (DARE) apply_keep_bits(p, m, local, f);
+                if constexpr (DARE) apply_keep_bits(p, m, local, seg.numel, f);
                 if (amb_hi_m >= 0.0f) {            // wave-uniform and rare: this pair's threshold is still provisional
 #pragma unroll
                     for (int j = 0; j < 8; j++) hit |= (__builtin_fabsf(f[j]) >= t_m) && (__builtin_fabsf(f[j]) <= amb_hi_m);
@@ -1322,7 +1328,7 @@ __device__ __forceinline__ void stock_agreeing(const TiesParams &p, int vote_sgn
             load_rt(p.in_dt, vec, p.in[d], e, valid, g[d]);
 #pragma unroll
             for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(g[d][j]);
-            if constexpr (DARE) apply_keep_bits(p, d, e, g[d]);
+            if constexpr (DARE) apply_keep_bits(p, d, e, p.seg0.numel, g[d]);
             if (p.raw) continue;                                                                // model_stock: no filter, no election
             const float thr = __uint_as_float(p.state[d].threshold_bits);
 #pragma unroll
@@ -1561,6 +1567,7 @@ struct TiesCall {
     int vote_sgn;
     float probability;
     int rescale;
+    int mask_stream;                        // keep_bits is one shared Bernoulli stream (TiesParams::mask_stream)
     int model_stock;                        // ties_sum_extended: apply the model-stock factor (per-key delta form only)
     float cos_eps;
     int64_t row_len;                        // size of the key's last dimension
@@ -1695,7 +1702,8 @@ int run_ties(const TiesCall &c) {
     }
     MECHA_REQUIRE(c.workspace != nullptr && c.workspace_bytes >= need && mecha_aligned16(c.workspace),
                   "TIES workspace too small or unaligned: need %zu bytes, got %zu", need, c.workspace_bytes);
-    if (c.keep_bits != nullptr) MECHA_REQUIRE(!batched && c.base == nullptr, "DARE masks are supported on the per-key delta form only");
+    if (c.keep_bits != nullptr) MECHA_REQUIRE(c.mask_stream || (!batched && c.base == nullptr), "DARE masks in row form are supported on the per-key delta form only");
+    MECHA_REQUIRE(total_tiles * (TIES_TILE / 4) < (1ll << 32), "%lld tiles are beyond one launch of the flat merge kernel", total_tiles);
 
     bool vec = mecha_aligned16(c.out) && (c.base == nullptr || mecha_aligned16(c.base));
     for (int m = 0; m < c.n_deltas; m++) {
@@ -1716,6 +1724,7 @@ int run_ties(const TiesCall &c) {
     for (int m = 0; m < c.n_deltas; m++) p.in[m] = c.inputs[m];
     p.keep_bits = c.keep_bits;
     p.mask_words = batched ? 0 : (c.numel + 31) / 32;
+    p.mask_stream = c.mask_stream;
     p.n_deltas = c.n_deltas;
     p.in_dt = c.in_dt;
     p.out_dt = c.out_dt;
@@ -1956,6 +1965,27 @@ int mecha_batched_add_difference_ties(const void *base_arena, const void *const 
     return run_ties(c);
 }
 
+int mecha_batched_add_difference_dare(const void *base_arena, const void *const *model_arenas, int n_models, void *out_arena,
+                                      const mecha_segment *segments, const mecha_segment *segments_host, int n_segments,
+                                      int64_t total_elems, int in_dtype, int out_dtype, double k, float alpha, int vote_sgn,
+                                      float probability, int rescale, const uint32_t *mask_stream, int64_t mask_stream_bits,
+                                      float *thresholds_out, void *workspace, size_t workspace_bytes, uint32_t *seg_flags, void *stream) {
+    MECHA_REQUIRE(base_arena != nullptr, "base arena is NULL");
+    MECHA_REQUIRE(segments != nullptr && segments_host != nullptr && n_segments >= 1, "batched DARE needs host and device segment tables");
+    MECHA_REQUIRE(mask_stream != nullptr, "mask_stream is NULL (draw it with mecha_dare_draw_stream_host)");
+    for (int s = 0; s < n_segments; s++)
+        MECHA_REQUIRE((int64_t)n_models * segments_host[s].numel <= mask_stream_bits, "segment %d needs %lld mask bits, the stream holds %lld",
+                      s, (long long)n_models * (long long)segments_host[s].numel, (long long)mask_stream_bits);
+    TiesCall c{};
+    c.base = base_arena; c.inputs = model_arenas; c.n_deltas = n_models; c.out = out_arena; c.segs_dev = segments;
+    c.segs_host = segments_host; c.n_segs = n_segments; c.total_elems = total_elems; c.in_dt = in_dtype; c.out_dt = out_dtype;
+    c.k = k; c.alpha = alpha; c.vote_sgn = vote_sgn; c.probability = probability; c.rescale = rescale;
+    c.keep_bits = mask_stream; c.mask_stream = 1;
+    c.thresholds_out = thresholds_out; c.workspace = workspace;
+    c.workspace_bytes = workspace_bytes; c.flags = seg_flags; c.stream = stream;
+    return run_ties(c);
+}
+
 size_t mecha_model_stock_workspace_bytes(int n_models, int64_t numel, int64_t row_len) {
     if (n_models < 2) n_models = 2;
     if (row_len < 1) row_len = 1;
@@ -2017,7 +2047,7 @@ int mecha_dropout(const void *const *deltas, int n_models, const uint32_t *keep_
     }
     p.keep_bits = keep_bits; p.mask_words = (numel + 31) / 32; p.n = n_models; p.rescalar = rescalar;
     const int64_t blocks = ((numel + 7) / 8 + MECHA_BLOCK - 1) / MECHA_BLOCK;
-    MECHA_REQUIRE(blocks <= 0x7fffffff, "numel %lld is beyond one launch", (long long)numel);
+    MECHA_REQUIRE(blocks * MECHA_BLOCK < (1ll << 32), "numel %lld is beyond one launch (2^24 - 1 blocks of 2048 elements)", (long long)numel);
     hipStream_t s = static_cast<hipStream_t>(stream);
     MECHA_DISPATCH_DTYPES(in_dtype, out_dtype, {
         MECHA_LAUNCH(MK_STREAMING, (dropout_kernel<IN_DT, OUT_DT>), dim3((unsigned)blocks), dim3(MECHA_BLOCK), 0, s, p, out, numel, vec, flags);

@@ -50,7 +50,7 @@ log = logging.getLogger("sd_mecha_amd")
 @dataclass
 class FusedPlan:
     """A recipe the batched kernels cover end to end."""
-    kind: str                                   # "wsum" | "navg" | "ties" | "lora" | "rotate"
+    kind: str                                   # "wsum" | "navg" | "ties" | "lora" | "rotate" | "slerp" | "addperp" | "addsub" | "adddiff" | "dare"
     models: List[ModelRecipeNode]               # inputs in kernel order (ties: base first)
     params: Dict[str, Any] = field(default_factory=dict)
     fallback: Optional[ModelRecipeNode] = None  # `| model`: value of a key whose merge was skipped
@@ -99,10 +99,39 @@ def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
     if ident == "n_average":
         if recipe.args and all(isinstance(a, ModelRecipeNode) for a in recipe.args) and not recipe.kwargs and len(recipe.args) <= _lib.MAX_MODELS:
             return FusedPlan("navg", list(recipe.args), {}, fallback)
+    if ident == "slerp":                                                       # linear.py:43-61 on two models, scalar alpha
+        b = _bound(recipe)
+        alpha = _scalar(b.get("alpha"), 0.5) if "alpha" in b else 0.5
+        if isinstance(b.get("a"), ModelRecipeNode) and isinstance(b.get("b"), ModelRecipeNode) and alpha is not None:
+            return FusedPlan("slerp", [b["a"], b["b"]], {"alpha": alpha}, fallback)
+    if ident == "add_perpendicular":                                           # this package's fused shim of wrappers.py:42-64
+        b = _bound(recipe)
+        alpha = _scalar(b.get("alpha"), 1.0) if "alpha" in b else 1.0
+        ms = [b.get("a"), b.get("b"), b.get("c")]
+        if all(isinstance(m, ModelRecipeNode) for m in ms) and alpha is not None and not math.isclose(alpha, 0.0):
+            return FusedPlan("addperp", ms, {"alpha": alpha}, fallback)
     if ident == "add_difference":
         b = _bound(recipe)
         alpha = _scalar(b.get("alpha"), 1.0) if "alpha" in b else 1.0
         base, t = b.get("a"), b.get("b")
+        plain = isinstance(base, ModelRecipeNode) and alpha is not None and not math.isclose(alpha, 0.0)
+        if plain and isinstance(t, ModelRecipeNode):                           # linear.py:64-76 with a delta checkpoint
+            return FusedPlan("adddiff", [base, t], {"alpha": alpha}, fallback)
+        if plain and isinstance(t, MergeRecipeNode):
+            tid, targs = t.merge_method.identifier, t.args
+            if tid == "subtract" and len(targs) == 2 and all(isinstance(m, ModelRecipeNode) for m in targs):
+                return FusedPlan("addsub", [base, targs[0], targs[1]], {"alpha": alpha}, fallback)          # wrappers.py:9-39 with `c`
+            if tid == "perpendicular_component" and len(targs) == 2 and not t.kwargs:                      # wrappers.py:42-64
+                da, db = targs
+                if (all(isinstance(d, MergeRecipeNode) and d.merge_method.identifier == "subtract" and len(d.args) == 2
+                        and all(isinstance(m, ModelRecipeNode) for m in d.args) for d in (da, db))
+                        and _same_model(da.args[0], base) and _same_model(da.args[1], db.args[1])):
+                    return FusedPlan("addperp", [base, db.args[0], da.args[1]], {"alpha": alpha}, fallback)
+            if tid == "ties_sum_with_dropout":                                                            # wrappers.py:231-273
+                dare = _dare_params(t, base)
+                if dare is not None:
+                    models, params = dare
+                    return FusedPlan("dare", [base] + models, dict(params, alpha=alpha), fallback)
         if isinstance(base, ModelRecipeNode) and alpha is not None and isinstance(t, MergeRecipeNode) and t.merge_method.identifier == "ties_sum":
             k = _scalar(t.kwargs.get("k"), 1.0) if "k" in t.kwargs else 1.0
             vote = t.kwargs.get("vote_sgn")
@@ -137,6 +166,47 @@ def fuse(recipe: RecipeNode) -> Optional[FusedPlan]:
                 and not math.isclose(alpha, 0.0) and len(recipe.args) <= _lib.MAX_MODELS):
             return FusedPlan("ties", list(recipe.args), {"k": k, "alpha": alpha, "vote_sgn": vote}, fallback)
     return None
+
+
+def _literal(node, default):
+    """The python value of a literal hyper-parameter node (None node = the default); _MISSING for anything else."""
+    if node is None:
+        return default
+    if isinstance(node, LiteralRecipeNode) and not isinstance(node.value, Mapping):
+        return node.value
+    return _MISSING
+
+
+_MISSING = object()
+
+
+def _dare_params(t: MergeRecipeNode, base: ModelRecipeNode):
+    """([models], params) of a ties_sum_with_dropout node the batched DARE path covers (ties.py:10-50): every delta is
+    subtract(model, base), scalar probability not close to 1, della_eps == 0, apply_median False, and apply_stock True
+    (ties.py:90: with False the Model-Stock factor is applied, which takes the per-key path)."""
+    kw = t.kwargs
+    vals = {name: _literal(kw.get(name), default) for name, default in
+            (("probability", 0.9), ("della_eps", 0.0), ("rescale", True), ("k", 0.2), ("vote_sgn", False), ("apply_stock", False),
+             ("apply_median", False), ("seed", None))}
+    if any(v is _MISSING for v in vals.values()):
+        return None
+    p, seed = vals["probability"], vals["seed"]
+    if isinstance(p, bool) or not isinstance(p, (int, float)) or math.isclose(float(p), 1.0) or not math.isclose(float(vals["della_eps"]), 0.0):
+        return None
+    if vals["apply_median"] or not vals["apply_stock"] or not (seed is None or isinstance(seed, int)):
+        return None
+    if isinstance(vals["k"], bool) or not isinstance(vals["k"], (int, float)):
+        return None
+    models = []
+    for d in t.args:
+        if not (isinstance(d, MergeRecipeNode) and d.merge_method.identifier == "subtract" and len(d.args) == 2
+                and isinstance(d.args[0], ModelRecipeNode) and _same_model(d.args[1], base)):
+            return None
+        models.append(d.args[0])
+    if not models or len(models) >= _lib.MAX_MODELS:
+        return None
+    return models, {"k": float(vals["k"]), "vote_sgn": bool(vals["vote_sgn"]), "probability": float(p), "rescale": bool(vals["rescale"]),
+                    "seed": seed}
 
 
 def _same_model(a: RecipeNode, b: RecipeNode) -> bool:
@@ -461,9 +531,61 @@ class HipBackend:
                 arenas[0].data_ptr(), _lib.ptr_array([a.data_ptr() for a in arenas[1:]]), len(arenas) - 1, out.data_ptr(),
                 segs_dev.data_ptr(), ctypes.addressof(segs_host), n, layout.total_elems, in_dt, out_dt, plan.params["k"],
                 plan.params["alpha"], int(plan.params["vote_sgn"]), None, workspace.data_ptr(), workspace.numel(), flags.data_ptr(), stream)
+        elif plan.kind == "adddiff":
+            st = L.mecha_batched_add_difference(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(), segs_dev.data_ptr(), n,
+                                                layout.total_elems, in_dt, out_dt, plan.params["alpha"], flags.data_ptr(), stream)
+        elif plan.kind == "addsub":
+            st = L.mecha_batched_add_difference_sub(arenas[0].data_ptr(), arenas[1].data_ptr(), arenas[2].data_ptr(), out.data_ptr(),
+                                                    segs_dev.data_ptr(), n, layout.total_elems, in_dt, out_dt, plan.params["alpha"],
+                                                    flags.data_ptr(), stream)
+        elif plan.kind == "slerp":
+            st = L.mecha_batched_slerp(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(), segs_dev.data_ptr(), ctypes.addressof(segs_host),
+                                       n, layout.total_elems, in_dt, out_dt, plan.params["alpha"], workspace.data_ptr(), workspace.numel(),
+                                       flags.data_ptr(), stream)
+        elif plan.kind == "addperp":
+            st = L.mecha_batched_add_perpendicular(arenas[0].data_ptr(), arenas[1].data_ptr(), arenas[2].data_ptr(), out.data_ptr(),
+                                                   segs_dev.data_ptr(), ctypes.addressof(segs_host), n, layout.total_elems, in_dt, out_dt,
+                                                   plan.params["alpha"], workspace.data_ptr(), workspace.numel(), flags.data_ptr(), stream)
+        elif plan.kind == "dare":
+            bits, n_bits = self._dare_stream(plan, max(layout.numels))
+            st = L.mecha_batched_add_difference_dare(
+                arenas[0].data_ptr(), _lib.ptr_array([a.data_ptr() for a in arenas[1:]]), len(arenas) - 1, out.data_ptr(),
+                segs_dev.data_ptr(), ctypes.addressof(segs_host), n, layout.total_elems, in_dt, out_dt, plan.params["k"],
+                plan.params["alpha"], int(plan.params["vote_sgn"]), plan.params["probability"], int(plan.params["rescale"]),
+                bits.data_ptr(), n_bits, None, workspace.data_ptr(), workspace.numel(), flags.data_ptr(), stream)
         else:
             raise ValueError(plan.kind)
         _lib.check(st, f"batched {plan.kind}")
+
+    def prepare(self, plan: FusedPlan, max_numel: int) -> None:
+        """Before the first wave of a fused run.  DARE: the Bernoulli stream every key's masks are cut from (the reference seeds a
+        fresh generator per key, ties.py:29-31) is drawn once, for the largest key of the run, on a thread of its own beside
+        the staging of the first wave."""
+        if plan.kind != "dare":
+            return
+        n_bits = (len(plan.models) - 1) * int(max_numel)
+        have = getattr(self, "_dare", None)
+        ident = (mm._dare_seed(plan.params["seed"]), float(plan.params["probability"]))
+        if have is not None and have[0] == ident and have[1] >= n_bits:
+            return
+
+        def draw():
+            host = torch.empty((n_bits + 31) // 32 + 1, dtype=torch.int32, pin_memory=self.device.type == "cuda")
+            _lib.check(self.lib.mecha_dare_draw_stream_host(ident[0] & 0xFFFFFFFFFFFFFFFF, ident[1], n_bits, host.data_ptr()),
+                       "mecha_dare_draw_stream_host")
+            return host
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        self._dare = (ident, n_bits, pool.submit(draw), None)
+        pool.shutdown(wait=False)
+
+    def _dare_stream(self, plan: FusedPlan, max_numel: int):
+        ident, n_bits, fut, dev = self._dare
+        if (len(plan.models) - 1) * int(max_numel) > n_bits:
+            raise RuntimeError("the DARE mask stream was prepared for smaller keys than this wave holds")
+        if dev is None:
+            dev = fut.result().to(self.device)                 # once per run: the waves share it
+            self._dare = (ident, n_bits, fut, dev)
+        return dev, n_bits
 
     # most workspace one batched rotate call may take; a shape group that needs more is cut into several calls
     ROTATE_WORKSPACE_BYTES = 24 << 30
@@ -552,8 +674,10 @@ class HipBackend:
         flags.index_copy_(0, torch.from_numpy(idx).to(self.device), entry_flags)
 
     def workspace_bytes(self, plan: FusedPlan, layout: ArenaLayout) -> int:
-        if plan.kind == "ties":
+        if plan.kind in ("ties", "dare"):
             return int(self.lib.mecha_batched_ties_workspace_bytes(len(plan.models) - 1, len(layout.keys), layout.total_elems))
+        if plan.kind in ("slerp", "addperp"):
+            return int(self.lib.mecha_batched_reduce_workspace_bytes(len(layout.keys), layout.total_elems))
         return 0
 
 
@@ -858,6 +982,8 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     s_comp = backend.stream() if is_cuda else None
     s_copy_out = backend.stream() if is_cuda else None
 
+    if hasattr(backend, "prepare"):
+        backend.prepare(plan, max(n for _, n in items))
     host_threads = max(1, min(int(os.environ.get("MECHA_HOST_THREADS", "16")), os.cpu_count() or 1))
     writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     # the LoRA files' factors (pread + H2D + per-file tables) load on a thread of their own beside the staging of the first wave

@@ -39,9 +39,10 @@ class RecipeNode:
 class ModelRecipeNode(RecipeNode):
     """A checkpoint on disk (helpers.py:15-43 ``sd_mecha.model(path)``)."""
 
-    def __init__(self, path, config=None):
+    def __init__(self, path, config=None, merge_space="weight"):
         self.path = pathlib.Path(path)
         self.config = config                  # model config identifier, or None: inferred from the key names at merge time
+        self.merge_space = merge_space        # "weight" | "delta" (helpers.py:15-43): recorded in the recipe text only
 
     def __repr__(self):
         return f"model({str(self.path)!r})"
@@ -76,9 +77,10 @@ def value_to_node(v) -> RecipeNode:
     return LiteralRecipeNode(v)
 
 
-def model(path, config=None) -> ModelRecipeNode:
-    """helpers.py:15-43: ``config`` is a model config identifier ("sdxl-sgm", ...) or None to infer it."""
-    return ModelRecipeNode(path, config)
+def model(path, config=None, merge_space="weight") -> ModelRecipeNode:
+    """helpers.py:15-43: ``config`` is a model config identifier ("sdxl-sgm", ...) or None to infer it; ``merge_space`` says
+    whether the file holds weights or deltas (a delta checkpoint is what add_difference takes as `b`)."""
+    return ModelRecipeNode(path, config, merge_space)
 
 
 def literal(value) -> LiteralRecipeNode:
@@ -323,7 +325,7 @@ def serialize(recipe: RecipeNode, model_configs: Optional[Mapping[int, str]] = N
             return done[id(n)]
         if isinstance(n, ModelRecipeNode):
             config = (model_configs or {}).get(id(n)) or n.config or aux_configs.get(id(n)) or "structural"
-            ref = add(f"model {value(str(n.path))} model_config={value(config)} merge_space=\"weight\"")
+            ref = add(f"model {value(str(n.path))} model_config={value(config)} merge_space={value(n.merge_space)}")
         elif isinstance(n, LiteralRecipeNode):
             if isinstance(n.value, Mapping):
                 ref = value(n.value)
@@ -390,7 +392,7 @@ def _cmd_literal(positional, named):
 
 def _cmd_model(positional, named):
     config = named.get("model_config")
-    return ModelRecipeNode(pathlib.Path(positional[0]), None if config in (None, "structural") else config)
+    return ModelRecipeNode(pathlib.Path(positional[0]), None if config in (None, "structural") else config, named.get("merge_space", "weight"))
 
 
 def _cmd_merge(positional, named):

@@ -307,6 +307,69 @@ def gen_e2e(out):
     out["shapes_keys"] = np.array(list(shapes.keys()))
 
 
+def gen_e2e_plans(out):
+    """Round 3: the graph shapes the scheduler gained batched plans for, through the real sd_mecha.merge on the SAME four toy
+    checkpoints as gen_e2e (read back from e2e.npz): slerp (linear.py:43-61), the add_perpendicular graph (wrappers.py:42-64),
+    add_difference(a, b - c) (wrappers.py:9-39 with `c`), add_difference(a, delta model), and add_ties_with_dare-shaped graphs
+    (wrappers.py:231-273; ties.py:10-50) with apply_stock True (no Model-Stock factor, ties.py:90) and False (factor applied)."""
+    import safetensors.torch
+    from tqdm import tqdm
+
+    class quiet(tqdm):
+        def __init__(self, *a, **k):
+            k["disable"] = True
+            super().__init__(*a, **k)
+
+    g = np.load(HERE / "e2e.npz")
+    shapes = {"w.linear": (128, 96), "w.conv": (32, 16, 3, 3), "w.bias": (128,), "w.scalar": ()}
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        paths = []
+        for m in range(4):
+            state = {k: torch.from_numpy(g[f"e_m{m}_{k}"].view(np.int16).copy()).view(torch.bfloat16).reshape(s) for k, s in shapes.items()}
+            p = td / f"m{m}.safetensors"
+            safetensors.torch.save_file(state, str(p))
+            paths.append(p)
+        # a fifth checkpoint with an all-zero bias: slerp and perpendicular_component take their NaN branches on that key
+        state = {k: torch.from_numpy(g[f"e_m1_{k}"].view(np.int16).copy()).view(torch.bfloat16).reshape(s).clone() for k, s in shapes.items()}
+        state["w.bias"].zero_()
+        safetensors.torch.save_file(state, str(td / "z.safetensors"))
+        out["p_z_w.bias"] = bits(state["w.bias"])
+        ms = [sd_mecha.model(p) for p in paths]
+        z = sd_mecha.model(td / "z.safetensors")
+        kw = dict(threads=0, output_dtype=torch.bfloat16, tqdm=quiet)
+
+        def store(name, res):
+            res = {k: v for k, v in res.items() if k != "__metadata__"}
+            out[f"p_{name}_keys"] = np.array(sorted(res.keys()))
+            for k, v in res.items():
+                out[f"p_{name}_{k}"] = bits(v)
+
+        def addperp(a, b, c, alpha):
+            return linear.add_difference(a, linear.perpendicular_component(linear.subtract(a, c), linear.subtract(b, c)), alpha=alpha)
+
+        store("slerp", sd_mecha.merge(linear.slerp(ms[0], ms[1], alpha=0.3), **kw))
+        store("slerp_zero", sd_mecha.merge(linear.slerp(z, ms[2], alpha=0.6), **kw))                # |a| = 0 on w.bias: NaN -> lerp
+        store("slerp_nonfinite", sd_mecha.merge(linear.slerp(ms[0], ms[3], alpha=0.5) | ms[0], **kw))  # m3 has an inf: key from the fallback
+        store("addperp", sd_mecha.merge(addperp(ms[0], ms[1], ms[2], 0.7), **kw))
+        store("addperp_zero", sd_mecha.merge(addperp(z, ms[2], ms[1], 1.0), **kw))                   # a - c = 0 on w.bias: NaN -> zeros
+        store("addsub", sd_mecha.merge(linear.add_difference(ms[0], linear.subtract(ms[1], ms[2]), alpha=0.6) | ms[0], **kw))
+        store("adddiff", sd_mecha.merge(linear.add_difference(ms[0], sd_mecha.model(paths[1], merge_space="delta"), alpha=0.25), **kw))
+        deltas = [linear.subtract(m, ms[0]) for m in ms[1:3]]
+        for name, extra in (("dare_nostock", dict(apply_stock=True, seed=114514, probability=0.4, k=0.5)),
+                            ("dare_nostock_norescale", dict(apply_stock=True, seed=7, probability=0.9, k=1.0, rescale=False)),
+                            ("dare_default_seed", dict(apply_stock=True, probability=0.5, k=0.2))):
+            store(name, sd_mecha.merge(linear.add_difference(ms[0], ties.ties_sum_with_dropout(*deltas, **extra), alpha=1.0), **kw))
+        # apply_stock False (the wrapper's default): the Model-Stock factor is applied; 0-d keys raise in CosineSimilarity(dim=-1)
+        three = {k: s for k, s in shapes.items() if len(s) >= 1}
+        for m in range(3):
+            st = {k: torch.from_numpy(g[f"e_m{m}_{k}"].view(np.int16).copy()).view(torch.bfloat16).reshape(s) for k, s in three.items()}
+            safetensors.torch.save_file(st, str(td / f"s{m}.safetensors"))
+        ss = [sd_mecha.model(td / f"s{m}.safetensors") for m in range(3)]
+        sdeltas = [linear.subtract(m, ss[0]) for m in ss[1:]]
+        store("dare_stock", sd_mecha.merge(linear.add_difference(ss[0], ties.ties_sum_with_dropout(*sdeltas, seed=3, probability=0.4, k=0.5), alpha=0.8), **kw))
+
+
 def gen_e2e_mixed(out):
     """Executor semantics through the real sd_mecha.merge on checkpoints shaped like real ones: an int64
     position_ids key, an fp32 key and an EMPTY int64 key among bf16 keys (the reference casts every key to fp32 and the result
@@ -592,7 +655,7 @@ def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
     only = set(sys.argv[1:])
     for name, fn in [("streaming", gen_streaming), ("alpha_tensor", gen_alpha_tensor), ("ties", gen_ties), ("dare", gen_dare), ("stock_dropout", gen_stock_dropout),
-                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_mixed", gen_e2e_mixed), ("e2e_alias", gen_e2e_alias), ("e2e_lora", gen_e2e_lora), ("mecha_text", gen_mecha_text),
+                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_plans", gen_e2e_plans), ("e2e_mixed", gen_e2e_mixed), ("e2e_alias", gen_e2e_alias), ("e2e_lora", gen_e2e_lora), ("mecha_text", gen_mecha_text),
                      ("configs", gen_configs)]:
         if only and name not in only:
             continue

@@ -132,6 +132,19 @@ class OracleBackend:
                 res = O.weighted_sum(f32[0], f32[1], plan.params["alpha"])
             elif plan.kind == "navg":
                 res = O.n_average(f32)
+            elif plan.kind == "slerp":
+                res = O.slerp(f32[0], f32[1], plan.params["alpha"])
+            elif plan.kind == "addperp":
+                res = O.add_perpendicular(f32[0], f32[1], f32[2], plan.params["alpha"])
+            elif plan.kind == "addsub":
+                res = O.add_difference(f32[0], O.subtract(f32[1], f32[2]), plan.params["alpha"])
+            elif plan.kind == "adddiff":
+                res = O.add_difference(f32[0], f32[1], plan.params["alpha"])
+            elif plan.kind == "dare":
+                q = plan.params
+                ties = O.ties_sum_with_dropout([O.subtract(m, f32[0]) for m in f32[1:]], probability=q["probability"], rescale=q["rescale"],
+                                               k=q["k"], vote_sgn=q["vote_sgn"], apply_stock=True, seed=q["seed"])
+                res = O.add_difference(f32[0], ties, q["alpha"])
             elif plan.kind == "rotate":
                 res = O.rotate(f32[0].reshape(shapes[i]), f32[1].reshape(shapes[i]), alignment=float(plan.params["alignment"]),
                                alpha=plan.params["alpha"], centralization=plan.params["centralization"])

@@ -155,6 +155,77 @@ def test_fuser_recognises_the_benchmark_recipes(toy_models):
     assert text.splitlines()[0] == "version 0.1.0" and 'merge "ties_sum"' in text and 'merge "add_difference" &0' in text
 
 
+# ------------------------------------------------------------------ round 3: batched plans for the rest of north_star's streaming list
+@pytest.fixture(scope="module")
+def plan_models(toy_models, tmp_path_factory):
+    """toy_models + a copy of m1 with an all-zero bias (the NaN branches of slerp / perpendicular_component) + three files
+    without the 0-d key (the Model-Stock factor has no last dimension to take a cosine along)."""
+    import safetensors.torch
+    g, gp = load_golden("e2e"), load_golden("e2e_plans")
+    d = tmp_path_factory.mktemp("plans")
+    state = {k: bf16(g[f"e_m1_{k}"], s) for k, s in SHAPES.items()}
+    state["w.bias"] = bf16(gp["p_z_w.bias"], SHAPES["w.bias"])
+    safetensors.torch.save_file(state, str(d / "z.safetensors"))
+    for m in range(3):
+        safetensors.torch.save_file({k: bf16(g[f"e_m{m}_{k}"], s) for k, s in SHAPES.items() if len(s) >= 1}, str(d / f"s{m}.safetensors"))
+    return {"m": list(toy_models), "z": d / "z.safetensors", "s": [d / f"s{m}.safetensors" for m in range(3)]}
+
+
+def plan_recipes(amd, pm):
+    """{golden name: (recipe, the plan kind fuse() must give it or None)} -- the recipes of gen_golden.gen_e2e_plans."""
+    ms, z, ss = [amd.model(p) for p in pm["m"]], amd.model(pm["z"]), [amd.model(p) for p in pm["s"]]
+
+    def addperp(a, b, c, alpha):
+        return amd.add_difference(a, amd.perpendicular_component(amd.subtract(a, c), amd.subtract(b, c)), alpha=alpha)
+    deltas = [amd.subtract(m, ms[0]) for m in ms[1:3]]
+    sdeltas = [amd.subtract(m, ss[0]) for m in ss[1:]]
+    return {
+        "slerp": (amd.slerp(ms[0], ms[1], alpha=0.3), "slerp"),
+        "slerp_zero": (amd.slerp(z, ms[2], alpha=0.6), "slerp"),
+        "slerp_nonfinite": (amd.slerp(ms[0], ms[3], alpha=0.5) | ms[0], "slerp"),
+        "addperp": (addperp(ms[0], ms[1], ms[2], 0.7), "addperp"),
+        "addperp_zero": (addperp(z, ms[2], ms[1], 1.0), "addperp"),
+        "addsub": (amd.add_difference(ms[0], amd.subtract(ms[1], ms[2]), alpha=0.6) | ms[0], "addsub"),
+        "adddiff": (amd.add_difference(ms[0], amd.model(pm["m"][1], merge_space="delta"), alpha=0.25), "adddiff"),
+        "dare_nostock": (amd.add_difference(ms[0], amd.ties_sum_with_dropout(*deltas, apply_stock=True, seed=114514, probability=0.4, k=0.5), alpha=1.0), "dare"),
+        "dare_nostock_norescale": (amd.add_difference(ms[0], amd.ties_sum_with_dropout(*deltas, apply_stock=True, seed=7, probability=0.9, k=1.0, rescale=False), alpha=1.0), "dare"),
+        "dare_default_seed": (amd.add_difference(ms[0], amd.ties_sum_with_dropout(*deltas, apply_stock=True, probability=0.5, k=0.2), alpha=1.0), "dare"),
+        "dare_stock": (amd.add_difference(ss[0], amd.ties_sum_with_dropout(*sdeltas, seed=3, probability=0.4, k=0.5), alpha=0.8), "dare_stock"),
+    }
+
+
+def check_plan_result(result: dict, name: str, max_ulp=1):
+    from conftest import ulp_distance_half
+    g = load_golden("e2e_plans")
+    want = {str(k): g[f"p_{name}_{k}"] for k in g[f"p_{name}_keys"]}
+    got = {k: v for k, v in result.items() if k != "__metadata__"}
+    assert sorted(got) == sorted(want), (name, sorted(got), sorted(want))
+    for k, w in want.items():
+        d = ulp_distance_half(tensor_bits(got[k]).reshape(-1), w.reshape(-1))
+        assert d.max() <= max_ulp, (name, k, int(d.max()), float((d > 0).mean()))
+        assert tuple(got[k].shape) == SHAPES[k]
+
+
+PLAN_EXACT = {"addsub", "adddiff"}            # one fma per element: bit for bit; the others hold reductions or TIES sums (<= 1 ulp)
+
+
+@pytest.mark.parametrize("name", ["slerp", "slerp_zero", "slerp_nonfinite", "addperp", "addperp_zero", "addsub", "adddiff", "dare_nostock",
+                                  "dare_nostock_norescale", "dare_default_seed"])
+@pytest.mark.parametrize("buffer", [1 << 31, 1 << 16])
+def test_round3_plans_reproduce_reference_cpu(plan_models, name, buffer, tmp_path):
+    """merge() on the batched plans of round 3 against the reference's own sd_mecha.merge outputs (tests/golden/e2e_plans.npz),
+    scheduler on CPU with the oracle as the compute double: plan recognition, key routing (0-d and non-finite keys), fallbacks."""
+    import sd_mecha_amd as amd
+    from sd_mecha_amd import merging
+    from oracle_backend import OracleBackend
+    recipe, kind = plan_recipes(amd, plan_models)[name]
+    plan = merging.fuse(recipe)
+    assert plan is not None and plan.kind == kind
+    res = amd.merge(recipe, backend=OracleBackend(), merge_device="cpu", output_dtype=torch.bfloat16, total_buffer_size=buffer, threads=0)
+    check_plan_result(res, name, 0 if name in PLAN_EXACT else 1)
+    assert merging.last_stats["generic_keys"] == 0 and merging.last_stats["fused_keys"] == 4
+
+
 # ------------------------------------------------------------------ .mecha text (row f1)
 def _mecha_recipes(amd, d):
     ms = [amd.model(d / f"m{i}.safetensors") for i in range(3)]
