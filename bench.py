@@ -159,7 +159,7 @@ class Job:
             st = lib.mecha_batched_add_difference_dare(
                 self.arenas[0].data_ptr(), self.model_ptrs, self.n_models - 1, self.out.data_ptr(), self.segs_dev.data_ptr(),
                 ctypes.addressof(self.segs_host), len(L.keys), L.total_elems, _lib.BF16, _lib.BF16, 0.2, 1.0, 0, self.dare_p, 1,
-                self.mask_stream.data_ptr(), self.mask_bits, None, self.ws.data_ptr(), self.ws.numel(), self.flags.data_ptr(), stream)
+                self.mask_stream.data_ptr(), self.mask_bits, 0, 0.0, None, None, None, self.ws.data_ptr(), self.ws.numel(), self.flags.data_ptr(), stream)
         else:
             st = lib.mecha_batched_weighted_sum(self.arenas[0].data_ptr(), self.arenas[1].data_ptr(), self.out.data_ptr(),
                                                 self.segs_dev.data_ptr(), len(L.keys), L.total_elems, _lib.BF16, _lib.BF16, 0.5,

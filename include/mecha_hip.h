@@ -375,15 +375,20 @@ int mecha_batched_add_difference_ties(const void *base_arena, const void *const 
                                       float alpha, int vote_sgn, float *thresholds_out, void *workspace,
                                       size_t workspace_bytes, uint32_t *seg_flags, void *stream);
 
-/* Batched DARE (wrappers.py:231-273 with apply_stock == True, della_eps == 0, apply_median == False):
- *   add_difference(base, ties_sum_with_dropout(m_i - base ..., probability, rescale, k, vote_sgn, seed), alpha)
+/* Batched DARE (wrappers.py:231-273, della_eps == 0, apply_median == False):
+ *   add_difference(base, ties_sum_with_dropout(m_i - base ..., probability, rescale, k, vote_sgn, seed, apply_stock), alpha)
  * for every key of the arenas.  `mask_stream`: DEVICE copy of mecha_dare_draw_stream_host's output, at least
  * n_models * (largest key) bits.  Thresholds are those of the MASKED deltas (ties.py:33-34), by the radix-select passes.
- * Workspace: mecha_batched_ties_workspace_bytes. */
+ * model_stock != 0 (the reference's apply_stock == False, its default, ties.py:90) applies the Model-Stock factor per slice of
+ * each key's last dimension: `row_lens` (DEVICE) / `row_lens_host` (HOST) int64[n_segments] hold that dimension per key
+ * (numel for 1-D keys; 0-d keys have none -- the reference raises, the caller must keep them out), 2..8 models.
+ * Workspace: mecha_batched_dare_workspace_bytes (total_rows = sum of numel / row_len over the keys, 0 without the factor). */
+size_t mecha_batched_dare_workspace_bytes(int n_models, int n_segments, int64_t total_elems, int64_t total_rows);
 int mecha_batched_add_difference_dare(const void *base_arena, const void *const *model_arenas, int n_models, void *out_arena,
                                       const mecha_segment *segments, const mecha_segment *segments_host, int n_segments,
                                       int64_t total_elems, int in_dtype, int out_dtype, double k, float alpha, int vote_sgn,
                                       float probability, int rescale, const uint32_t *mask_stream, int64_t mask_stream_bits,
+                                      int model_stock, float cos_eps, const int64_t *row_lens, const int64_t *row_lens_host,
                                       float *thresholds_out, void *workspace, size_t workspace_bytes, uint32_t *seg_flags,
                                       void *stream);
 

@@ -86,8 +86,9 @@ SIGNATURES = {
     "mecha_batched_slerp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p]),
     "mecha_batched_perpendicular_component": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_p, c_sz, c_p, c_p]),
     "mecha_batched_add_perpendicular": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p]),
+    "mecha_batched_dare_workspace_bytes": (c_sz, [c_i, c_i, c_i64, c_i64]),
     "mecha_batched_add_difference_dare": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_i, c_i, c_d, c_f, c_i, c_f, c_i, c_p, c_i64,
-                                                c_p, c_p, c_sz, c_p, c_p]),
+                                                c_i, c_f, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
     "mecha_lora_accumulate": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mecha_batched_lora_accumulate": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mecha_rotate_workspace_bytes": (c_sz, [c_i64, c_i64]),

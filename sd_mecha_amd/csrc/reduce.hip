@@ -26,6 +26,9 @@ struct RedScalars {            // written by finish, read by apply / fixup
     float sa, sb, so, nl;      // slerp: sin((1-alpha) omega), sin(alpha omega), sin(omega), lerp(|a|, |b|, alpha)
     float proj;                // perpendicular: sum((a/|a|) * (b/|a|))
     uint32_t any_nan;          // set by apply
+    uint32_t bad_out;          // batched form: apply saw a non-finite result (reported only if the key is not rewritten by fixup)
+    float rna, rnb, rso;       // batched form: RN(1 / na), RN(1 / nb), RN(1 / so) for the three-instruction division
+    uint32_t fast_div;         // batched form: 1 = that division is safe for this key's divisors
 };
 
 struct RedWorkspace {
@@ -281,7 +284,7 @@ constexpr int BRED_TILE = MECHA_BLOCK * 8;           // 2048 elements: one vecto
 
 struct BredTile { long long elem; int seg; int valid; };   // first element inside the arena, key, elements in the tile
 
-struct BredGlobals { uint32_t any_nan; uint32_t pad[3]; };
+struct BredGlobals { uint32_t n_nan_keys; uint32_t pad[3]; };
 
 struct BredParams {
     const void *a, *b, *c;
@@ -294,6 +297,7 @@ struct BredParams {
     double *partial;                    // [n_tiles][3]
     RedScalars *sc;                     // [n_segs]
     BredGlobals *globals;
+    int *nan_keys;                      // [n_segs] keys whose result held a NaN, in the order the apply pass met them
     float alpha, alpha_m1;
     int small;
     int vec_ok;
@@ -345,12 +349,19 @@ __device__ __forceinline__ void bred_operands(const BredParams &p, int64_t e, in
             if constexpr (MODE == RM_ADDPERP) c[j] = (j < valid) ? load1<IN_DT>(p.c, e + j) : 0.0f;
         }
     }
+    // fma(v, 0, poison) stays 0 while every input is finite and turns NaN after an inf or a NaN (two values per v_pk_fma_f32)
+    f32x2 poison = {0.0f, 0.0f};
+    const f32x2 zero2 = {0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(x[j]) | nonfinite_f32(y[j]);
+    for (int j = 0; j < 8; j += 2) {
+        poison = __builtin_elementwise_fma(f32x2{x[j], x[j + 1]}, zero2, poison);
+        poison = __builtin_elementwise_fma(f32x2{y[j], y[j + 1]}, zero2, poison);
+        if constexpr (MODE == RM_ADDPERP) poison = __builtin_elementwise_fma(f32x2{c[j], c[j + 1]}, zero2, poison);
+    }
+    bad_in |= (poison.x != poison.x) | (poison.y != poison.y);
     if constexpr (MODE == RM_ADDPERP) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            bad_in |= nonfinite_f32(c[j]);
             a0[j] = x[j];
             x[j] = x[j] - c[j];                       // subtract (linear.py:101)
             y[j] = y[j] - c[j];
@@ -358,41 +369,63 @@ __device__ __forceinline__ void bred_operands(const BredParams &p, int64_t e, in
     }
 }
 
+// Two tiles per block: with two input streams one vector position per thread keeps only 32 bytes per lane in flight (4.7 TB/s
+// on the SDXL x2 job; a read-only pass with 64 bytes per lane reaches 7).  Both tiles' loads are issued before either is reduced.
+constexpr int BRED_U = 2;
 template <int MODE, int IN_DT>
 __global__ __launch_bounds__(MECHA_BLOCK) void bred_reduce_kernel(BredParams p) {
-    const BredTile rec = p.tiles[blockIdx.x];
     const int local = threadIdx.x * 8;
-    const int valid = rec.valid - local >= 8 ? 8 : (rec.valid - local > 0 ? rec.valid - local : 0);
-    double sxx = 0.0, syy = 0.0, sxy = 0.0;
-    bool bad_in = false;
-    if (valid > 0) {
-        float x[8], y[8], a0[8];
-        bred_operands<MODE, IN_DT>(p, rec.elem + local, valid, p.vec_ok && valid == 8, x, y, a0, bad_in);
+    BredTile rec[BRED_U];
+    int valid[BRED_U];
+    float x[BRED_U][8], y[BRED_U][8], a0[8];
+    bool bad_in[BRED_U];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const double dx = x[j], dy = y[j];
-            sxx = __builtin_fma(dx, dx, sxx);
-            syy = __builtin_fma(dy, dy, syy);
-            sxy = __builtin_fma(dx, dy, sxy);
+    for (int u = 0; u < BRED_U; u++) {
+        const long long t = (long long)blockIdx.x * BRED_U + u;
+        rec[u] = (t < p.n_tiles) ? p.tiles[t] : BredTile{0, 0, 0};
+        valid[u] = rec[u].valid - local >= 8 ? 8 : (rec[u].valid - local > 0 ? rec[u].valid - local : 0);
+        bad_in[u] = false;
+    }
+#pragma unroll
+    for (int u = 0; u < BRED_U; u++)
+        if (valid[u] > 0) bred_operands<MODE, IN_DT>(p, rec[u].elem + local, valid[u], p.vec_ok && valid[u] == 8, x[u], y[u], a0, bad_in[u]);
+    __shared__ double wsum[MECHA_BLOCK / 64][BRED_U][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int u = 0; u < BRED_U; u++) {
+        // A lane's 8 elements are summed in fp32, in index order (three fp64 fmas and two conversions per element made this pass
+        // VALU-bound: 4.5 TB/s); everything above a lane -- the wave, the block, the key's tiles -- is summed in fp64.  The fp32
+        // part rounds at 2^-24 of a lane's own partial sum; torch's own reduction is an fp32 cascade throughout.
+        float fxx = 0.0f, fyy = 0.0f, fxy = 0.0f;
+        if (valid[u] > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                fxx = __builtin_fmaf(x[u][j], x[u][j], fxx);
+                fyy = __builtin_fmaf(y[u][j], y[u][j], fyy);
+                fxy = __builtin_fmaf(x[u][j], y[u][j], fxy);
+            }
+        }
+        double sxx = fxx, syy = fyy, sxy = fxy;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sxx += __shfl_down(sxx, off, 64);
+            syy += __shfl_down(syy, off, 64);
+            sxy += __shfl_down(sxy, off, 64);
+        }
+        if (lane == 0) { wsum[wave][u][0] = sxx; wsum[wave][u][1] = syy; wsum[wave][u][2] = sxy; }
+        if (bad_in[u] && p.flags != nullptr) atomicOr(p.flags + rec[u].seg, MECHA_FLAG_INPUT_NONFINITE);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * BRED_U) {
+        const int u = threadIdx.x / 3, c = threadIdx.x % 3;
+        const long long t = (long long)blockIdx.x * BRED_U + u;
+        if (t < p.n_tiles) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < MECHA_BLOCK / 64; w++) tot += wsum[w][u][c];
+            p.partial[t * 3 + c] = tot;
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sxx += __shfl_down(sxx, off, 64);
-        syy += __shfl_down(syy, off, 64);
-        sxy += __shfl_down(sxy, off, 64);
-    }
-    __shared__ double wsum[MECHA_BLOCK / 64][3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { wsum[wave][0] = sxx; wsum[wave][1] = syy; wsum[wave][2] = sxy; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < MECHA_BLOCK / 64; w++) t += wsum[w][threadIdx.x];
-        p.partial[(long long)blockIdx.x * 3 + threadIdx.x] = t;
-    }
-    if (bad_in && p.flags != nullptr) atomicOr(p.flags + rec.seg, MECHA_FLAG_INPUT_NONFINITE);
 }
 
 template <int MODE>
@@ -419,12 +452,32 @@ __global__ __launch_bounds__(64) void bred_finish_kernel(BredParams p) {
         sc.proj = (float)(s2 / ((double)sc.na * (double)sc.na));
     }
     sc.any_nan = 0;
+    sc.bad_out = 0;
+    // x / d as q0 = RN(x y), q = RN(q0 + RN(x - d q0) y) with y = RN(1 / d): the correctly rounded quotient (Markstein) unless d's
+    // significand is all ones or an intermediate leaves the normal range; divisors outside [2^-60, 2^60] keep the IEEE division
+    auto safe = [](float d) {
+        const uint32_t b = __float_as_uint(d) & 0x7fffffffu;
+        return b >= 0x21800000u && b <= 0x5d800000u && (b & 0x7fffffu) != 0x7fffffu;
+    };
+    sc.rna = 1.0f / sc.na; sc.rnb = 1.0f / sc.nb; sc.rso = 1.0f / sc.so;
+    sc.fast_div = (MODE == RM_SLERP && safe(sc.na) && safe(sc.nb) && safe(sc.so)) ? 1u : 0u;
     p.sc[s] = sc;
 }
 
-template <int MODE>
+__device__ __forceinline__ float bred_div(float x, float d, float rd) {
+    const float q0 = x * rd;
+    return __builtin_fmaf(__builtin_fmaf(-d, q0, x), rd, q0);
+}
+
+template <int MODE, bool FAST>
 __device__ __forceinline__ float bred_formula(const RedScalars &sc, float x, float y) {
     if constexpr (MODE == RM_SLERP) {
+        // three IEEE divisions per element cost ~35 of the ~47 VALU instructions per element this pass can afford at HBM speed
+        if constexpr (FAST) {
+            const float an = bred_div(x, sc.na, sc.rna), bn = bred_div(y, sc.nb, sc.rnb);
+            const float q = bred_div(an * sc.sa + bn * sc.sb, sc.so, sc.rso);
+            return q * sc.nl;
+        }
         const float an = x / sc.na, bn = y / sc.nb;              // linear.py:49-50
         float q = (an * sc.sa + bn * sc.sb) / sc.so;             // linear.py:55-57
         return q * sc.nl;                                        // linear.py:58
@@ -445,9 +498,22 @@ __global__ __launch_bounds__(MECHA_BLOCK) void bred_apply_kernel(BredParams p) {
     bool bad_in = false, any_nan = false, bad_out = false;
     bred_operands<MODE, IN_DT>(p, e, valid, vec, x, y, a0, bad_in);     // the loads are issued before the key's scalars are needed
     const RedScalars sc = p.sc[rec.seg];
+    bool redo = false;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        float q = bred_formula<MODE>(sc, x[j], y[j]);
+        float q = sc.fast_div ? bred_formula<MODE, true>(sc, x[j], y[j]) : bred_formula<MODE, false>(sc, x[j], y[j]);
+        // non-zero operands below 2^-40 could leave the normal range on the way (the divisors lie in [2^-60, 2^60]): IEEE division then
+        if constexpr (MODE == RM_SLERP)
+            redo |= (((__float_as_uint(x[j]) & 0x7fffffffu) - 1u) < 0x2b800000u - 1u) | (((__float_as_uint(y[j]) & 0x7fffffffu) - 1u) < 0x2b800000u - 1u);
+        r[j] = q;
+    }
+    if (redo && sc.fast_div) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = bred_formula<MODE, false>(sc, x[j], y[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float q = r[j];
         if (j < valid) any_nan |= (q != q);
         if constexpr (MODE == RM_ADDPERP) q = __builtin_fmaf(q, p.alpha, a0[j]);      // add_difference(a, perp, alpha)  (linear.py:76)
         r[j] = q;
@@ -459,17 +525,26 @@ __global__ __launch_bounds__(MECHA_BLOCK) void bred_apply_kernel(BredParams p) {
         for (int j = 0; j < 8; j++)
             if (j < valid) store1<OUT_DT>(p.out, e + j, r[j]);
     }
-    if (any_nan) { atomicOr(&p.sc[rec.seg].any_nan, 1u); atomicOr(&p.globals->any_nan, 1u); }
-    if (bad_out && p.flags != nullptr) atomicOr(p.flags + rec.seg, MECHA_FLAG_OUTPUT_NONFINITE);
+    if (any_nan && atomicOr(&p.sc[rec.seg].any_nan, 1u) == 0u) p.nan_keys[atomicAdd(&p.globals->n_nan_keys, 1u)] = rec.seg;
+    // a key with a NaN is rewritten as a whole by fixup: what its discarded result looked like must not reach the flag word
+    // (check_finite_output sees the method's RETURN value, merging.py:297-308).  bred_flags_kernel sorts that out per key.
+    if (bad_out) atomicOr(&p.sc[rec.seg].bad_out, 1u);
+}
+
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_flags_kernel(BredParams p) {
+    const int s = blockIdx.x * MECHA_BLOCK + threadIdx.x;
+    if (s >= p.n_segs || p.flags == nullptr) return;
+    if (p.sc[s].bad_out != 0 && p.sc[s].any_nan == 0) atomicOr(p.flags + s, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
 // The reference's `if res.isnan().any()` branches, for the keys the apply pass noted (rare: an all-zero tensor, identical inputs).
 template <int MODE, int IN_DT, int OUT_DT>
 __global__ __launch_bounds__(MECHA_BLOCK) void bred_fixup_kernel(BredParams p) {
-    if (p.globals->any_nan == 0) return;
-    for (long long t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {
+    const uint32_t n_list = p.globals->n_nan_keys;
+    for (uint32_t li = 0; li < n_list; li++) {
+    const int s = p.nan_keys[li];
+    for (long long t = p.tile_start[s] + blockIdx.x; t < p.tile_start[s + 1]; t += gridDim.x) {
         const BredTile rec = p.tiles[t];
-        if (p.sc[rec.seg].any_nan == 0) continue;                 // block-uniform
         const int local = threadIdx.x * 8;
         const int valid = rec.valid - local >= 8 ? 8 : (rec.valid - local > 0 ? rec.valid - local : 0);
         if (valid == 0) continue;
@@ -506,11 +581,12 @@ __global__ __launch_bounds__(MECHA_BLOCK) void bred_fixup_kernel(BredParams p) {
         }
         if (bad_out && p.flags != nullptr) atomicOr(p.flags + rec.seg, MECHA_FLAG_OUTPUT_NONFINITE);
     }
+    }
 }
 
 size_t bred_align(size_t v) { return (v + 255) / 256 * 256; }
 
-struct BredLayout { size_t tile_start_off, tiles_off, partial_off, sc_off, globals_off, total; size_t max_tiles; };
+struct BredLayout { size_t tile_start_off, tiles_off, partial_off, sc_off, globals_off, nan_keys_off, total; size_t max_tiles; };
 BredLayout bred_layout(int n_segs, int64_t total_elems) {
     BredLayout w;
     w.max_tiles = (size_t)(total_elems > 0 ? total_elems : 0) / BRED_TILE + (size_t)n_segs;
@@ -520,6 +596,7 @@ BredLayout bred_layout(int n_segs, int64_t total_elems) {
     w.partial_off = off;    off = bred_align(off + sizeof(double) * 3 * w.max_tiles);
     w.sc_off = off;         off = bred_align(off + sizeof(RedScalars) * (size_t)n_segs);
     w.globals_off = off;    off = bred_align(off + sizeof(BredGlobals));
+    w.nan_keys_off = off;   off = bred_align(off + sizeof(int) * (size_t)n_segs);
     w.total = off;
     return w;
 }
@@ -554,6 +631,7 @@ int run_batched_reduce(const void *a, const void *b, const void *c, void *out, c
     p.partial = reinterpret_cast<double *>(ws + w.partial_off);
     p.sc = reinterpret_cast<RedScalars *>(ws + w.sc_off);
     p.globals = reinterpret_cast<BredGlobals *>(ws + w.globals_off);
+    p.nan_keys = reinterpret_cast<int *>(ws + w.nan_keys_off);
     p.alpha = alpha; p.alpha_m1 = alpha - 1.0f; p.small = (alpha < 0.5f && alpha > -0.5f) ? 1 : 0;
     p.vec_ok = (mecha_aligned16(a) && mecha_aligned16(b) && mecha_aligned16(out) && (c == nullptr || mecha_aligned16(c))) ? 1 : 0;
     p.flags = flags;
@@ -565,10 +643,11 @@ int run_batched_reduce(const void *a, const void *b, const void *c, void *out, c
     const unsigned grid = (unsigned)n_tiles;
     const unsigned fix_grid = (unsigned)(n_tiles < 2048 ? n_tiles : 2048);
     MECHA_DISPATCH_DTYPES(in_dt, out_dt, {
-        MECHA_LAUNCH(MK_RED_REDUCE, (bred_reduce_kernel<MODE, IN_DT>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p);
+        MECHA_LAUNCH(MK_RED_REDUCE, (bred_reduce_kernel<MODE, IN_DT>), dim3((grid + BRED_U - 1) / BRED_U), dim3(MECHA_BLOCK), 0, s, p);
         MECHA_LAUNCH(MK_RED_FINISH, (bred_finish_kernel<MODE>), dim3((unsigned)n_segs), dim3(64), 0, s, p);
         MECHA_LAUNCH(MK_RED_APPLY, (bred_apply_kernel<MODE, IN_DT, OUT_DT>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p);
         MECHA_LAUNCH(MK_RED_FIXUP, (bred_fixup_kernel<MODE, IN_DT, OUT_DT>), dim3(fix_grid), dim3(MECHA_BLOCK), 0, s, p);
+        MECHA_LAUNCH(MK_RED_FIXUP, bred_flags_kernel, dim3((unsigned)((n_segs + MECHA_BLOCK - 1) / MECHA_BLOCK)), dim3(MECHA_BLOCK), 0, s, p);
     });
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;

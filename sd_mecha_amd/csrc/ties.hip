@@ -581,7 +581,27 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
     const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
     TileCursor cur;
 
+    // Exact zeros are counted per lane in registers and added to bin 0 at the flush: a DARE-masked delta is 90 % zeros (and deltas
+    // of fine-tunes hold runs of them), and 64 lanes adding to ONE LDS word serialise (30.8 ms per pass for SDXL x3 with masks
+    // against ~5 ms for dense deltas).  A zero can only match the all-zero prefix, whose bin in every pass is 0.
+    uint32_t zeros[CAP];
+#pragma unroll
+    for (int d = 0; d < CAP; d++) zeros[d] = 0;
     auto flush = [&](int s) {
+#pragma unroll
+        for (int d = 0; d < CAP; d++) {
+            if (d < nd) {                                               // block-uniform
+                uint32_t tot = zeros[d];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+                if (tot && (threadIdx.x & 63) == 0) {
+                    atomicAdd(&lds_hist[d * TIES_BINS], tot);
+                    // pass 1 also keeps the number of exact zeros per pair: a rank inside them IS the threshold 0 (ties_scan_kernel<1>)
+                    if constexpr (PASS == 1) atomicAdd(&p.counts[(int64_t)s * p.n_deltas + d0 + d].eq_lo, (unsigned long long)tot);
+                }
+            }
+            zeros[d] = 0;
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < nd * TIES_BINS; i += MECHA_BLOCK) {
             const uint32_t c = lds_hist[i];
@@ -607,7 +627,8 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
             for (int d = 0; d < CAP; d++) {
                 if (d < nd) {
                     const SelectState &st = p.state[(int64_t)cur.s * p.n_deltas + d0 + d];
-                    active[d] = !p.bracket || st.mode == MODE_FAILED;
+                    // pipeline A: only the pairs whose bracket missed; pipeline B: every pair (pass 1), then those pass 1 did not settle
+                    active[d] = p.bracket ? st.mode == MODE_FAILED : (PASS == 1 || st.mode != MODE_RESOLVED);
                     if constexpr (PASS > 1) want[d] = st.prefix;
                 }
             }
@@ -643,7 +664,8 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
                         const uint32_t bits = __float_as_uint(v[d][j]) & 0x7fffffffu;        // |delta|
                         bool hit = j < valid;
                         if constexpr (PASS > 1) hit = hit && ((bits & C::prefix_mask) == want[d]);
-                        if (hit) atomicAdd(&lds_hist[d * TIES_BINS + ((bits >> C::shift) & (C::bins - 1))], 1u);
+                        if (hit && bits == 0u) zeros[d] += 1u;
+                        else if (hit) atomicAdd(&lds_hist[d * TIES_BINS + ((bits >> C::shift) & (C::bins - 1))], 1u);
                     }
                 }
             }
@@ -666,13 +688,29 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_scan_kernel(TiesParams p, do
     uint32_t *h = p.hist + sd * TIES_BINS;
     SelectState st = p.state[sd];
     if (p.bracket && st.mode != MODE_FAILED) return;
+    if constexpr (PASS > 1) {
+        if (!p.bracket && st.mode == MODE_RESOLVED) return;                  // settled by pass 1 (its histogram is already clear)
+    }
     if constexpr (PASS == 1) {
         st.kth = ties_kth(one_minus_k, get_segment(p, s).numel);
         st.prefix = 0; st.threshold_bits = 0; st.kth_rem = st.kth;
+        if (!p.bracket) st.mode = MODE_PENDING;
     }
     int bin; unsigned long long below; uint32_t count;
     find_bin(h, st.kth_rem, bin, below, count, wave_tot, &sel, &sel_below, &sel_count);
     for (int i = threadIdx.x; i < TIES_BINS; i += MECHA_BLOCK) h[i] = 0;     // ready for the next pass / the next call
+    if constexpr (PASS == 1) {
+        // the kth-smallest |delta| is an exact zero (a DARE-masked delta is mostly zeros): that is the threshold, the other two
+        // passes have nothing to find for this pair
+        if (!p.bracket && st.kth <= p.counts[sd].eq_lo) {
+            if (threadIdx.x == 0) {
+                st.mode = MODE_RESOLVED; st.threshold_bits = 0; st.prefix = 0;
+                if (thresholds_out != nullptr) thresholds_out[sd] = 0.0f;
+                p.state[sd] = st;
+            }
+            return;
+        }
+    }
     if (threadIdx.x == 0) {
         if (bin < 0) { bin = 0; below = 0; }                     // unreachable for kth <= numel; keeps the state defined
         st.prefix |= ((uint32_t)bin) << C::shift;
@@ -1308,29 +1346,62 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_tile_records_kernel(const me
 // Per-key, delta form, 2..8 deltas.  Three kernels after the thresholds are known: row sums (dot products and squared
 // norms, fp64: torch's fp32 reduction order is not fixed), the factor per row, the apply pass.
 struct StockParams {
-    int64_t row_len, n_rows;
+    int64_t row_len, n_rows;    // per key form: the key's last dimension and its number of rows
+    const int64_t *row_lens;    // batched: device [n_segs] last dimension of each key ...
+    const int64_t *row_starts;  //          ... and the first row of each key in `sums` / `t` (prefix of numel / row_len)
     double *sums;               // [n_rows][2 n - 1]: n squared norms, then n - 1 dot products
     float *t;                   // [n_rows]
     float cos_eps;
 };
 constexpr int STOCK_MAX = 8;
 
-// g[d][j] for the 8 elements at e (filtered by threshold, DARE mask, and agreement with the elected sign) and the agree count
+// row_starts[s] = rows of the keys before s; row_starts[n_segs] = all rows (one block; n_segs is a few thousand)
+__global__ __launch_bounds__(1024) void ties_stock_rows_kernel(const mecha_segment *segs, const int64_t *row_lens, int n_segs, int64_t *row_starts) {
+    __shared__ long long part[1024];
+    const int per = (n_segs + 1023) / 1024;
+    const int lo = (threadIdx.x * per < n_segs) ? threadIdx.x * per : n_segs;
+    const int hi = (lo + per < n_segs) ? lo + per : n_segs;
+    long long sum = 0;
+    for (int i = lo; i < hi; i++) sum += segs[i].numel / row_lens[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; i++) { long long v = part[i]; part[i] = run; run += v; }
+        row_starts[n_segs] = run;
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) { row_starts[i] = run; run += segs[i].numel / row_lens[i]; }
+}
+
+// g[d][j] for the 8 elements at `local` of key s (delta = model - base where there is a base; filtered by threshold, DARE mask,
+// and agreement with the elected sign), the agree count, and the base values
 template <bool DARE>
-__device__ __forceinline__ void stock_agreeing(const TiesParams &p, int vote_sgn, int64_t e, int valid, bool vec, float (&g)[STOCK_MAX][8],
-                                               float (&cnt)[8], bool &bad_in) {
+__device__ __forceinline__ void stock_agreeing(const TiesParams &p, int vote_sgn, int s, const mecha_segment &seg, int64_t local, int valid, bool vec,
+                                               float (&g)[STOCK_MAX][8], float (&cnt)[8], float (&b)[8], bool &bad_in) {
+    const int64_t e = seg.offset + local;
     float vote[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { vote[j] = 0.0f; cnt[j] = 0.0f; }
+    for (int j = 0; j < 8; j++) { vote[j] = 0.0f; cnt[j] = 0.0f; b[j] = 0.0f; }
+    if (p.base != nullptr) {
+        load_rt(p.in_dt, vec, p.base, e, valid, b);
+#pragma unroll
+        for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(b[j]);
+    }
 #pragma unroll
     for (int d = 0; d < STOCK_MAX; d++) {
         if (d < p.n_deltas) {
             load_rt(p.in_dt, vec, p.in[d], e, valid, g[d]);
 #pragma unroll
             for (int j = 0; j < 8; j++) bad_in |= nonfinite_f32(g[d][j]);
-            if constexpr (DARE) apply_keep_bits(p, d, e, p.seg0.numel, g[d]);
+            if (p.base != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) g[d][j] = g[d][j] - b[j];                             // subtract (linear.py:101)
+            }
+            if constexpr (DARE) apply_keep_bits(p, d, local, seg.numel, g[d]);
             if (p.raw) continue;                                                                // model_stock: no filter, no election
-            const float thr = __uint_as_float(p.state[d].threshold_bits);
+            const float thr = __uint_as_float(p.state[(int64_t)s * p.n_deltas + d].threshold_bits);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 g[d][j] = g[d][j] * ((__builtin_fabsf(g[d][j]) >= thr) ? 1.0f : 0.0f);          // filter_top_k (ties.py:128-132)
@@ -1356,109 +1427,136 @@ __device__ __forceinline__ void stock_agreeing(const TiesParams &p, int vote_sgn
     }
 }
 
+// Both stock kernels walk tiles like the radix passes (a block owns a contiguous run of tiles, the cursor tracks the key): one
+// key with p.seg0, or every key of an arena.
 template <bool DARE>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_reduce_kernel(TiesParams p, StockParams sp, int vote_sgn, uint32_t *flags) {
-    const int64_t numel = p.seg0.numel;
     const int n = p.n_deltas, width = 2 * n - 1;
-    bool bad_in = false;
-    for (int64_t e = ((int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x) * 8; e < numel; e += (int64_t)gridDim.x * MECHA_BLOCK * 8) {
-        const int valid = (numel - e >= 8) ? 8 : (int)(numel - e);
-        float g[STOCK_MAX][8], cnt[8];
-        stock_agreeing<DARE>(p, vote_sgn, e, valid, p.vec_ok && valid == 8, g, cnt, bad_in);
-        double acc[2 * STOCK_MAX - 1];
-        int64_t row = e / sp.row_len;
-        int64_t row_end = (row + 1) * sp.row_len;
-        auto clear = [&]() {
+    const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
+    const long long t0 = (long long)blockIdx.x * chunk;
+    const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
+    TileCursor cur;
+    for (long long t = t0; t < t1; t++) {
+        cursor_seek(p, t, cur);
+        const mecha_segment seg = cur.seg;
+        const int64_t row_len = sp.row_lens != nullptr ? sp.row_lens[cur.s] : sp.row_len;
+        const int64_t row_base = sp.row_starts != nullptr ? sp.row_starts[cur.s] : 0;
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+            const int64_t local = (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
+            const int valid = (local >= seg.numel) ? 0 : ((seg.numel - local >= 8) ? 8 : (int)(seg.numel - local));
+            bool bad_in = false;
+            float g[STOCK_MAX][8], cnt[8], b[8];
+            if (valid > 0) stock_agreeing<DARE>(p, vote_sgn, cur.s, seg, local, valid, p.vec_ok && valid == 8, g, cnt, b, bad_in);
+            double acc[2 * STOCK_MAX - 1];
+            int64_t row = local / row_len;
+            int64_t row_end = (row + 1) * row_len;
+            auto clear = [&]() {
 #pragma unroll
-            for (int i = 0; i < 2 * STOCK_MAX - 1; i++) acc[i] = 0.0;
-        };
-        auto flush = [&](int64_t r) {
+                for (int i = 0; i < 2 * STOCK_MAX - 1; i++) acc[i] = 0.0;
+            };
+            auto flush = [&](int64_t r) {
 #pragma unroll
-            for (int i = 0; i < 2 * STOCK_MAX - 1; i++)
-                if (i < width && acc[i] != 0.0) atomicAdd(&sp.sums[r * width + i], acc[i]);
-        };
-        clear();
-        // whole wave inside one row (rows of >= 512 elements, mostly): reduce across lanes first, one lane adds
-        const int64_t first_row = __shfl(row, 0, 64);
-        const bool lane_one_row = (e + valid <= row_end);
-        const bool uniform = __ballot(lane_one_row && row == first_row) == ~0ull;        // all 64 lanes active and in one row
+                for (int i = 0; i < 2 * STOCK_MAX - 1; i++)
+                    if (i < width && acc[i] != 0.0) atomicAdd(&sp.sums[(row_base + r) * width + i], acc[i]);
+            };
+            clear();
+            // whole wave inside one row (rows of >= 512 elements, mostly): reduce across lanes first, one lane adds
+            const int64_t first_row = __shfl(row, 0, 64);
+            const bool lane_one_row = valid == 8 && (local + valid <= row_end);
+            const bool uniform = __ballot(lane_one_row && row == first_row) == ~0ull;        // all 64 lanes active, full, in one row
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j < valid) {
-                if (e + j >= row_end) { flush(row); clear(); row += 1; row_end += sp.row_len; if (e + j >= row_end) { row = (e + j) / sp.row_len; row_end = (row + 1) * sp.row_len; } }
+            for (int j = 0; j < 8; j++) {
+                if (j < valid) {
+                    if (local + j >= row_end) { flush(row); clear(); row += 1; row_end += row_len; if (local + j >= row_end) { row = (local + j) / row_len; row_end = (row + 1) * row_len; } }
 #pragma unroll
-                for (int d = 0; d < STOCK_MAX; d++) {
-                    if (d < n) {
-                        acc[d] += (double)g[d][j] * (double)g[d][j];
-                        if (d + 1 < n) acc[n + d] += (double)g[d][j] * (double)g[d + 1][j];
+                    for (int d = 0; d < STOCK_MAX; d++) {
+                        if (d < n) {
+                            acc[d] += (double)g[d][j] * (double)g[d][j];
+                            if (d + 1 < n) acc[n + d] += (double)g[d][j] * (double)g[d + 1][j];
+                        }
                     }
                 }
             }
-        }
-        if (uniform) {
+            if (uniform) {
 #pragma unroll
-            for (int i = 0; i < 2 * STOCK_MAX - 1; i++) {
-                if (i < width) {
+                for (int i = 0; i < 2 * STOCK_MAX - 1; i++) {
+                    if (i < width) {
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+                        for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+                    }
                 }
+                if ((threadIdx.x & 63) == 0) flush(row);
+            } else if (valid > 0) {
+                flush(row);
             }
-            if ((threadIdx.x & 63) == 0) flush(row);
-        } else {
-            flush(row);
+            if (bad_in && flags != nullptr) atomicOr(flags + (p.tile_start == nullptr ? 0 : cur.s), MECHA_FLAG_INPUT_NONFINITE);
         }
     }
-    if (bad_in && flags != nullptr) atomicOr(flags, MECHA_FLAG_INPUT_NONFINITE);
 }
 
-__global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_t_kernel(StockParams sp, int n) {
-    const int64_t r = (int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x;
-    if (r >= sp.n_rows) return;
-    const double *s = sp.sums + r * (2 * n - 1);
-    double mean = 0.0;
-    for (int i = 0; i + 1 < n; i++) {
-        // cosine_similarity: x.y / (max(|x|, eps) max(|y|, eps))
-        const double nx = fmax(sqrt(s[i]), (double)sp.cos_eps), ny = fmax(sqrt(s[i + 1]), (double)sp.cos_eps);
-        mean += s[n + i] / (nx * ny);
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_t_kernel(StockParams sp, int n, const int64_t *n_rows_dev) {
+    const int64_t n_rows = n_rows_dev != nullptr ? *n_rows_dev : sp.n_rows;
+    for (int64_t r = (int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * MECHA_BLOCK) {
+        const double *s = sp.sums + r * (2 * n - 1);
+        double mean = 0.0;
+        for (int i = 0; i + 1 < n; i++) {
+            // cosine_similarity: x.y / (max(|x|, eps) max(|y|, eps))
+            const double nx = fmax(sqrt(s[i]), (double)sp.cos_eps), ny = fmax(sqrt(s[i + 1]), (double)sp.cos_eps);
+            mean += s[n + i] / (nx * ny);
+        }
+        const float c = (float)(mean / (double)(n - 1));
+        sp.t[r] = ((float)n * c) / (1.0f + (float)(n - 1) * c);                                  // ties.py:158
     }
-    const float c = (float)(mean / (double)(n - 1));
-    sp.t[r] = ((float)n * c) / (1.0f + (float)(n - 1) * c);                                  // ties.py:158
 }
 
 template <bool DARE>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_stock_apply_kernel(TiesParams p, StockParams sp, MergeExtra x, void *out, uint32_t *flags) {
-    const int64_t numel = p.seg0.numel;
-    bool bad_in = false, bad_out = false;
-    for (int64_t e = ((int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x) * 8; e < numel; e += (int64_t)gridDim.x * MECHA_BLOCK * 8) {
-        const int valid = (numel - e >= 8) ? 8 : (int)(numel - e);
-        const bool vec = p.vec_ok && valid == 8;
-        float g[STOCK_MAX][8], cnt[8], r[8];
-        stock_agreeing<DARE>(p, x.vote_sgn, e, valid, vec, g, cnt, bad_in);
+    const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
+    const long long t0 = (long long)blockIdx.x * chunk;
+    const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
+    TileCursor cur;
+    for (long long t = t0; t < t1; t++) {
+        cursor_seek(p, t, cur);
+        const mecha_segment seg = cur.seg;
+        const int64_t row_len = sp.row_lens != nullptr ? sp.row_lens[cur.s] : sp.row_len;
+        const int64_t row_base = sp.row_starts != nullptr ? sp.row_starts[cur.s] : 0;
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+            const int64_t local = (t - cur.first) * TIES_TILE + (int64_t)u * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
+            if (local >= seg.numel) continue;
+            const int valid = (seg.numel - local >= 8) ? 8 : (int)(seg.numel - local);
+            const bool vec = p.vec_ok && valid == 8;
+            bool bad_in = false, bad_out = false;
+            float g[STOCK_MAX][8], cnt[8], b[8], r[8];
+            stock_agreeing<DARE>(p, x.vote_sgn, cur.s, seg, local, valid, vec, g, cnt, b, bad_in);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float acc = 0.0f;
+            for (int j = 0; j < 8; j++) {
+                float acc = 0.0f;
 #pragma unroll
-            for (int d = 0; d < STOCK_MAX; d++)
-                if (d < p.n_deltas) acc += g[d][j];                                              // filtered_delta.sum(dim=0)
-            const float t = (j < valid) ? sp.t[(e + j) / sp.row_len] : 0.0f;
-            float q;
-            if (p.raw) {
-                q = t * (acc / cnt[j]);                                                          // t * (sum(deltas) / len(deltas))  (ties.py:141-143)
-                // torch.nan_to_num with its defaults: nan -> 0, +-inf -> the largest finite fp32 of that sign
-                if (q != q) q = 0.0f;
-                else if (nonfinite_f32(q)) q = __builtin_copysignf(3.4028234663852886e38f, q);
-            } else {
-                q = (acc * t) / cnt[j];                                                          // ties.py:92
-                if (nonfinite_f32(q)) q = 0.0f;                                                  // nan_to_num(nan=0, posinf=0, neginf=0)
+                for (int d = 0; d < STOCK_MAX; d++)
+                    if (d < p.n_deltas) acc += g[d][j];                                              // filtered_delta.sum(dim=0)
+                const float tt = (j < valid) ? sp.t[row_base + (local + j) / row_len] : 0.0f;
+                float q;
+                if (p.raw) {
+                    q = tt * (acc / cnt[j]);                                                         // t * (sum(deltas) / len(deltas))  (ties.py:141-143)
+                    // torch.nan_to_num with its defaults: nan -> 0, +-inf -> the largest finite fp32 of that sign
+                    if (q != q) q = 0.0f;
+                    else if (nonfinite_f32(q)) q = __builtin_copysignf(3.4028234663852886e38f, q);
+                } else {
+                    q = (acc * tt) / cnt[j];                                                         // ties.py:92
+                    if (nonfinite_f32(q)) q = 0.0f;                                                  // nan_to_num(nan=0, posinf=0, neginf=0)
+                }
+                if (x.has_rescale) q = q / x.rescale_div;                                            // ties.py:50
+                if (p.base != nullptr) q = __builtin_fmaf(q, x.alpha, b[j]);                         // base.addcmul(ties, alpha)  (linear.py:76)
+                bad_out |= (j < valid) && nonfinite_f32(q);
+                r[j] = q;
             }
-            if (x.has_rescale) q = q / x.rescale_div;                                            // ties.py:50
-            bad_out |= (j < valid) && nonfinite_f32(q);
-            r[j] = q;
+            store_rt(p.out_dt, vec, out, seg.offset + local, valid, r);
+            if ((bad_in | bad_out) && flags != nullptr)
+                atomicOr(flags + (p.tile_start == nullptr ? 0 : cur.s), (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
         }
-        store_rt(p.out_dt, vec, out, e, valid, r);
     }
-    if ((bad_in | bad_out) && flags != nullptr)
-        atomicOr(flags, (bad_in ? MECHA_FLAG_INPUT_NONFINITE : 0u) | (bad_out ? MECHA_FLAG_OUTPUT_NONFINITE : 0u));
 }
 
 // ------------------------------------------------------------------------------------------------ dropout (n-supermario)
@@ -1571,6 +1669,8 @@ struct TiesCall {
     int model_stock;                        // ties_sum_extended: apply the model-stock factor (per-key delta form only)
     float cos_eps;
     int64_t row_len;                        // size of the key's last dimension
+    const int64_t *row_lens_dev;            // batched + model_stock: every key's last dimension (DEVICE [n_segs]) ...
+    const int64_t *row_lens_host;           // ... and the HOST copy
     float *thresholds_out;
     void *workspace;
     size_t workspace_bytes;
@@ -1692,13 +1792,23 @@ int run_ties(const TiesCall &c) {
     const WorkspaceLayout w = layout(c.n_deltas, n_segs, batched ? c.total_elems : c.numel);
     size_t need = w.total;
     int64_t n_rows = 0;
+    size_t row_starts_bytes = 0;
     if (c.model_stock) {
-        MECHA_REQUIRE(!batched && c.base == nullptr, "the model-stock factor is supported on the per-key delta form only");
         MECHA_REQUIRE(c.n_deltas >= 2 && c.n_deltas <= STOCK_MAX, "the model-stock factor needs 2..%d deltas (got %d): the reference's "
                       "torch.stack of an empty list of cosines raises for one delta", STOCK_MAX, c.n_deltas);
-        MECHA_REQUIRE(c.row_len >= 1 && c.numel % c.row_len == 0, "row_len (%lld) must divide numel (%lld)", (long long)c.row_len, (long long)c.numel);
-        n_rows = c.numel / c.row_len;
-        need += stock_bytes(c.n_deltas, n_rows);
+        if (batched) {
+            MECHA_REQUIRE(c.row_lens_dev != nullptr && c.row_lens_host != nullptr, "batched model-stock factor needs the keys' last dimensions (host and device)");
+            for (int s = 0; s < c.n_segs; s++) {
+                MECHA_REQUIRE(c.row_lens_host[s] >= 1 && c.segs_host[s].numel % c.row_lens_host[s] == 0, "segment %d: row_len (%lld) must divide numel (%lld)",
+                              s, (long long)c.row_lens_host[s], (long long)c.segs_host[s].numel);
+                n_rows += c.segs_host[s].numel / c.row_lens_host[s];
+            }
+            row_starts_bytes = align_up(sizeof(int64_t) * ((size_t)c.n_segs + 1), 256);
+        } else {
+            MECHA_REQUIRE(c.row_len >= 1 && c.numel % c.row_len == 0, "row_len (%lld) must divide numel (%lld)", (long long)c.row_len, (long long)c.numel);
+            n_rows = c.numel / c.row_len;
+        }
+        need += row_starts_bytes + stock_bytes(c.n_deltas, n_rows);
     }
     MECHA_REQUIRE(c.workspace != nullptr && c.workspace_bytes >= need && mecha_aligned16(c.workspace),
                   "TIES workspace too small or unaligned: need %zu bytes, got %zu", need, c.workspace_bytes);
@@ -1771,21 +1881,28 @@ int run_ties(const TiesCall &c) {
     if (c.model_stock) {
         StockParams sp{};
         sp.row_len = c.row_len; sp.n_rows = n_rows; sp.cos_eps = c.cos_eps;
-        sp.sums = reinterpret_cast<double *>(ws + w.total);
-        sp.t = reinterpret_cast<float *>(ws + w.total + align_up(sizeof(double) * (size_t)n_rows * (2 * c.n_deltas - 1), 256));
+        char *stock = ws + w.total;
+        if (batched) {
+            sp.row_lens = c.row_lens_dev;
+            sp.row_starts = reinterpret_cast<const int64_t *>(stock);
+            MECHA_LAUNCH(MK_TIES_INDEX, ties_stock_rows_kernel, dim3(1), dim3(1024), 0, s, c.segs_dev, c.row_lens_dev, n_segs, reinterpret_cast<int64_t *>(stock));
+            stock += row_starts_bytes;
+        }
+        sp.sums = reinterpret_cast<double *>(stock);
+        sp.t = reinterpret_cast<float *>(stock + align_up(sizeof(double) * (size_t)n_rows * (2 * c.n_deltas - 1), 256));
         MECHA_CHECK_HIP(hipMemsetAsync(sp.sums, 0, sizeof(double) * (size_t)n_rows * (2 * c.n_deltas - 1), s));
-        const int64_t vecs = (c.numel + 7) / 8;
-        const unsigned sgrid = (unsigned)((vecs + MECHA_BLOCK - 1) / MECHA_BLOCK < MECHA_MAX_GRID ? (vecs + MECHA_BLOCK - 1) / MECHA_BLOCK : MECHA_MAX_GRID);
-        const unsigned tgrid = (unsigned)((n_rows + MECHA_BLOCK - 1) / MECHA_BLOCK);
+        const unsigned sgrid = (unsigned)(total_tiles < 4 * MECHA_MAX_GRID ? total_tiles : 4 * MECHA_MAX_GRID);
+        const int64_t tblocks = (n_rows + MECHA_BLOCK - 1) / MECHA_BLOCK;
+        const unsigned tgrid = (unsigned)(tblocks < 65536 ? tblocks : 65536);
         if (dare) {
             launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s);
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_reduce_kernel<true>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, c.vote_sgn, c.flags);
-            MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas);
+            MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas, (const int64_t *)nullptr);
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<true>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, c.out, c.flags);
         } else {
             launch_radix<false>(p, grid, one_minus_k, c.thresholds_out, s);
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_reduce_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, c.vote_sgn, c.flags);
-            MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas);
+            MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas, (const int64_t *)nullptr);
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, c.out, c.flags);
         }
     } else if (!bracket) {
@@ -1965,10 +2082,19 @@ int mecha_batched_add_difference_ties(const void *base_arena, const void *const 
     return run_ties(c);
 }
 
+size_t mecha_batched_dare_workspace_bytes(int n_models, int n_segments, int64_t total_elems, int64_t total_rows) {
+    if (n_models < 1) n_models = 1;
+    if (n_segments < 1) n_segments = 1;
+    size_t need = layout(n_models, n_segments, total_elems).total;
+    if (total_rows > 0) need += align_up(sizeof(int64_t) * ((size_t)n_segments + 1), 256) + stock_bytes(n_models, total_rows);
+    return need;
+}
+
 int mecha_batched_add_difference_dare(const void *base_arena, const void *const *model_arenas, int n_models, void *out_arena,
                                       const mecha_segment *segments, const mecha_segment *segments_host, int n_segments,
                                       int64_t total_elems, int in_dtype, int out_dtype, double k, float alpha, int vote_sgn,
                                       float probability, int rescale, const uint32_t *mask_stream, int64_t mask_stream_bits,
+                                      int model_stock, float cos_eps, const int64_t *row_lens, const int64_t *row_lens_host,
                                       float *thresholds_out, void *workspace, size_t workspace_bytes, uint32_t *seg_flags, void *stream) {
     MECHA_REQUIRE(base_arena != nullptr, "base arena is NULL");
     MECHA_REQUIRE(segments != nullptr && segments_host != nullptr && n_segments >= 1, "batched DARE needs host and device segment tables");
@@ -1981,6 +2107,7 @@ int mecha_batched_add_difference_dare(const void *base_arena, const void *const 
     c.segs_host = segments_host; c.n_segs = n_segments; c.total_elems = total_elems; c.in_dt = in_dtype; c.out_dt = out_dtype;
     c.k = k; c.alpha = alpha; c.vote_sgn = vote_sgn; c.probability = probability; c.rescale = rescale;
     c.keep_bits = mask_stream; c.mask_stream = 1;
+    c.model_stock = model_stock; c.cos_eps = cos_eps; c.row_lens_dev = row_lens; c.row_lens_host = row_lens_host;
     c.thresholds_out = thresholds_out; c.workspace = workspace;
     c.workspace_bytes = workspace_bytes; c.flags = seg_flags; c.stream = stream;
     return run_ties(c);
@@ -2012,6 +2139,7 @@ int mecha_model_stock(const void *const *deltas, int n_models, void *out, int64_
     }
     p.n_deltas = n_models; p.in_dt = in_dtype; p.out_dt = out_dtype; p.raw = 1; p.vec_ok = vec ? 1 : 0;
     p.seg0 = mecha_segment{0, numel}; p.n_segs = 1;
+    p.total_tiles = (numel + TIES_TILE - 1) / TIES_TILE;
     char *ws = static_cast<char *>(workspace);
     StockParams sp{};
     sp.row_len = row_len; sp.n_rows = n_rows; sp.cos_eps = cos_eps;
@@ -2019,12 +2147,12 @@ int mecha_model_stock(const void *const *deltas, int n_models, void *out, int64_
     sp.t = reinterpret_cast<float *>(ws + align_up(sizeof(double) * (size_t)n_rows * (2 * n_models - 1), 256));
     hipStream_t s = static_cast<hipStream_t>(stream);
     MECHA_CHECK_HIP(hipMemsetAsync(sp.sums, 0, sizeof(double) * (size_t)n_rows * (2 * n_models - 1), s));
-    const int64_t vecs = (numel + 7) / 8;
-    const unsigned sgrid = (unsigned)((vecs + MECHA_BLOCK - 1) / MECHA_BLOCK < MECHA_MAX_GRID ? (vecs + MECHA_BLOCK - 1) / MECHA_BLOCK : MECHA_MAX_GRID);
-    const unsigned tgrid = (unsigned)((n_rows + MECHA_BLOCK - 1) / MECHA_BLOCK);
+    const unsigned sgrid = (unsigned)(p.total_tiles < 4 * MECHA_MAX_GRID ? p.total_tiles : 4 * MECHA_MAX_GRID);
+    const int64_t tblocks = (n_rows + MECHA_BLOCK - 1) / MECHA_BLOCK;
+    const unsigned tgrid = (unsigned)(tblocks < 65536 ? tblocks : 65536);
     MergeExtra x{};
     MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_reduce_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, 0, flags);
-    MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, n_models);
+    MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, n_models, (const int64_t *)nullptr);
     MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, out, flags);
     MECHA_CHECK_HIP(hipGetLastError());
     return MECHA_OK;

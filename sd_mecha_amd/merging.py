@@ -182,18 +182,21 @@ _MISSING = object()
 
 def _dare_params(t: MergeRecipeNode, base: ModelRecipeNode):
     """([models], params) of a ties_sum_with_dropout node the batched DARE path covers (ties.py:10-50): every delta is
-    subtract(model, base), scalar probability not close to 1, della_eps == 0, apply_median False, and apply_stock True
-    (ties.py:90: with False the Model-Stock factor is applied, which takes the per-key path)."""
+    subtract(model, base), scalar probability not close to 1, della_eps == 0, apply_median False.  apply_stock False (the
+    default) APPLIES the Model-Stock factor (ties.py:90), which takes 2..8 deltas."""
     kw = t.kwargs
     vals = {name: _literal(kw.get(name), default) for name, default in
             (("probability", 0.9), ("della_eps", 0.0), ("rescale", True), ("k", 0.2), ("vote_sgn", False), ("apply_stock", False),
-             ("apply_median", False), ("seed", None))}
+             ("apply_median", False), ("seed", None), ("cos_eps", 1e-6))}
     if any(v is _MISSING for v in vals.values()):
         return None
     p, seed = vals["probability"], vals["seed"]
     if isinstance(p, bool) or not isinstance(p, (int, float)) or math.isclose(float(p), 1.0) or not math.isclose(float(vals["della_eps"]), 0.0):
         return None
-    if vals["apply_median"] or not vals["apply_stock"] or not (seed is None or isinstance(seed, int)):
+    if vals["apply_median"] or not (seed is None or isinstance(seed, int)) or isinstance(vals["cos_eps"], bool) or not isinstance(vals["cos_eps"], (int, float)):
+        return None
+    model_stock = not vals["apply_stock"]
+    if model_stock and not 2 <= len(t.args) <= 8:
         return None
     if isinstance(vals["k"], bool) or not isinstance(vals["k"], (int, float)):
         return None
@@ -206,7 +209,7 @@ def _dare_params(t: MergeRecipeNode, base: ModelRecipeNode):
     if not models or len(models) >= _lib.MAX_MODELS:
         return None
     return models, {"k": float(vals["k"]), "vote_sgn": bool(vals["vote_sgn"]), "probability": float(p), "rescale": bool(vals["rescale"]),
-                    "seed": seed}
+                    "seed": seed, "model_stock": model_stock, "cos_eps": float(vals["cos_eps"])}
 
 
 def _same_model(a: RecipeNode, b: RecipeNode) -> bool:
@@ -548,11 +551,17 @@ class HipBackend:
                                                    plan.params["alpha"], workspace.data_ptr(), workspace.numel(), flags.data_ptr(), stream)
         elif plan.kind == "dare":
             bits, n_bits = self._dare_stream(plan, max(layout.numels))
+            rows_dev = rows_host = None
+            if plan.params["model_stock"]:                          # the factor is per slice of the key's last dimension (ties.py:154)
+                rows_host = np.asarray([shape[-1] for shape in shapes], dtype=np.int64)
+                rows_dev = torch.from_numpy(rows_host).to(self.device)
             st = L.mecha_batched_add_difference_dare(
                 arenas[0].data_ptr(), _lib.ptr_array([a.data_ptr() for a in arenas[1:]]), len(arenas) - 1, out.data_ptr(),
                 segs_dev.data_ptr(), ctypes.addressof(segs_host), n, layout.total_elems, in_dt, out_dt, plan.params["k"],
                 plan.params["alpha"], int(plan.params["vote_sgn"]), plan.params["probability"], int(plan.params["rescale"]),
-                bits.data_ptr(), n_bits, None, workspace.data_ptr(), workspace.numel(), flags.data_ptr(), stream)
+                bits.data_ptr(), n_bits, int(plan.params["model_stock"]), plan.params["cos_eps"],
+                rows_dev.data_ptr() if rows_dev is not None else None, rows_host.ctypes.data if rows_host is not None else None,
+                None, workspace.data_ptr(), workspace.numel(), flags.data_ptr(), stream)
         else:
             raise ValueError(plan.kind)
         _lib.check(st, f"batched {plan.kind}")
@@ -673,9 +682,12 @@ class HipBackend:
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mecha_batched_lora_accumulate")
         flags.index_copy_(0, torch.from_numpy(idx).to(self.device), entry_flags)
 
-    def workspace_bytes(self, plan: FusedPlan, layout: ArenaLayout) -> int:
-        if plan.kind in ("ties", "dare"):
+    def workspace_bytes(self, plan: FusedPlan, layout: ArenaLayout, shapes=None) -> int:
+        if plan.kind == "ties":
             return int(self.lib.mecha_batched_ties_workspace_bytes(len(plan.models) - 1, len(layout.keys), layout.total_elems))
+        if plan.kind == "dare":
+            rows = sum(n // shape[-1] for n, shape in zip(layout.numels, shapes)) if plan.params["model_stock"] else 0
+            return int(self.lib.mecha_batched_dare_workspace_bytes(len(plan.models) - 1, len(layout.keys), layout.total_elems, rows))
         if plan.kind in ("slerp", "addperp"):
             return int(self.lib.mecha_batched_reduce_workspace_bytes(len(layout.keys), layout.total_elems))
         return 0
@@ -926,6 +938,8 @@ def _split_fusable(plan: Optional[FusedPlan], readers, items, header):
                     dt = None
                     break
                 dt = meta.dtype
+            if dt is not None and plan.kind == "dare" and plan.params["model_stock"] and len(header[key].shape) == 0:
+                dt = None                   # no last dimension to take the cosine along: the per-key body raises like the reference's
         if dt is None:
             generic.append((key, n))
         else:
@@ -1049,7 +1063,7 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             if is_cuda:
                 s_comp.wait_event(bs["ev_h2d"])
             flags = torch.zeros(len(L.keys), dtype=torch.int32, device=dev)
-            nbytes = backend.workspace_bytes(plan, L)
+            nbytes = backend.workspace_bytes(plan, L, [tuple(header[k].shape) for k in L.keys])
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if nbytes else None
             if plan.kind == "lora" and hasattr(backend, "run_lora_tables"):
                 tables = lora_store.tables(L, header)
@@ -1163,7 +1177,7 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
                 a[n:].zero_()                                          # the arena's tail gap stays finite
             segs_host, segs_dev = L.host_segments(), L.device_segments(dev)
             flags = torch.zeros(1, dtype=torch.int32, device=dev)
-            nbytes = backend.workspace_bytes(plan, L)
+            nbytes = backend.workspace_bytes(plan, L, [tuple(meta.shape)])
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev) if nbytes else None
             skip = ()
             if plan.kind == "lora" and hasattr(backend, "run_lora_tables"):

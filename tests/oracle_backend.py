@@ -110,7 +110,7 @@ class OracleBackend:
     def stream(self):
         return None
 
-    def workspace_bytes(self, plan, layout):
+    def workspace_bytes(self, plan, layout, shapes=None):
         return 0
 
     def run_fused(self, plan, arenas, out, layout, segs_dev, segs_host, flags, workspace, shapes=None):
@@ -142,9 +142,10 @@ class OracleBackend:
                 res = O.add_difference(f32[0], f32[1], plan.params["alpha"])
             elif plan.kind == "dare":
                 q = plan.params
-                ties = O.ties_sum_with_dropout([O.subtract(m, f32[0]) for m in f32[1:]], probability=q["probability"], rescale=q["rescale"],
-                                               k=q["k"], vote_sgn=q["vote_sgn"], apply_stock=True, seed=q["seed"])
-                res = O.add_difference(f32[0], ties, q["alpha"])
+                shp = shapes[i] if q["model_stock"] else (n,)
+                ties = O.ties_sum_with_dropout([O.subtract(m, f32[0]).reshape(shp) for m in f32[1:]], probability=q["probability"], rescale=q["rescale"],
+                                               k=q["k"], vote_sgn=q["vote_sgn"], apply_stock=not q["model_stock"], cos_eps=q["cos_eps"], seed=q["seed"])
+                res = O.add_difference(f32[0], np.ascontiguousarray(ties).reshape(-1), q["alpha"])
             elif plan.kind == "rotate":
                 res = O.rotate(f32[0].reshape(shapes[i]), f32[1].reshape(shapes[i]), alignment=float(plan.params["alignment"]),
                                alpha=plan.params["alpha"], centralization=plan.params["centralization"])

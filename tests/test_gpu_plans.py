@@ -65,11 +65,11 @@ def test_batched_reductions_vs_oracle(oracle, dtype, out_dtype):
             want = {"slerp": lambda: oracle.slerp(f[0], f[1], 0.3), "perp": lambda: oracle.perpendicular_component(f[0], f[1]),
                     "addperp": lambda: oracle.add_perpendicular(f[0], f[1], f[2], 0.6)}[name]()
             got = out[o:o + m]
-            if out_dtype == "float32":
-                assert np.allclose(host_f32(got), want, rtol=3e-6, atol=1e-9), (name, s)
+            mag = np.abs(f[0]) + np.abs(f[1]) + (np.abs(f[2]) if name == "addperp" else 0)
+            if out_dtype == "float32":                              # fp32 out: a few fp32 ulps of the result, or of the operands where it cancels
+                assert (np.abs(host_f32(got) - want) <= 4e-6 * np.abs(want) + 1e-6 * mag).all(), (name, s)
                 continue
             d = ulp_distance_half(host_bits(got), oracle.from_f32(want, out_dtype))
-            mag = np.abs(f[0]) + np.abs(f[1]) + (np.abs(f[2]) if name == "addperp" else 0)
             noise = np.abs(host_f32(got) - want) <= 1e-6 * mag      # where the formula cancels, fp32 operand noise is the floor
             assert ((d <= 1) | noise).all() and (m < 64 or (d > 0).mean() <= 0.02), (name, s, int(d.max()))
         # nothing outside the keys was written
@@ -143,7 +143,7 @@ def test_batched_dare_vs_oracle(oracle, n_models, p, k, rescale, vote):
         flags.zero_()
         _lib.check(L.mecha_batched_add_difference_dare(arenas[0].data_ptr(), _lib.ptr_array([a.data_ptr() for a in arenas[1:]]), n_models,
                                                        out.data_ptr(), segs_dev.data_ptr(), ctypes.addressof(segs), n, total, _lib.BF16, _lib.BF16,
-                                                       k, 0.8, int(vote), p, int(rescale), stream_dev.data_ptr(), n_bits, thr.data_ptr(),
+                                                       k, 0.8, int(vote), p, int(rescale), stream_dev.data_ptr(), n_bits, 0, 0.0, None, None, thr.data_ptr(),
                                                        ws.data_ptr(), ws.numel(), flags.data_ptr(), _stream()), "batched dare")
         torch.cuda.synchronize()
     assert int(flags.sum().item()) == 0
@@ -164,7 +164,7 @@ def test_batched_dare_vs_oracle(oracle, n_models, p, k, rescale, vote):
     # a stream that is too short for the largest key is refused on the host
     assert L.mecha_batched_add_difference_dare(arenas[0].data_ptr(), _lib.ptr_array([a.data_ptr() for a in arenas[1:]]), n_models, out.data_ptr(),
                                                segs_dev.data_ptr(), ctypes.addressof(segs), n, total, _lib.BF16, _lib.BF16, k, 0.8, 0, p, 1,
-                                               stream_dev.data_ptr(), n_bits - 1, None, ws.data_ptr(), ws.numel(), flags.data_ptr(), _stream()) < 0
+                                               stream_dev.data_ptr(), n_bits - 1, 0, 0.0, None, None, None, ws.data_ptr(), ws.numel(), flags.data_ptr(), _stream()) < 0
 
 
 @pytest.mark.parametrize("name", ["slerp", "slerp_zero", "slerp_nonfinite", "addperp", "addperp_zero", "addsub", "adddiff", "dare_nostock",
@@ -220,17 +220,14 @@ def test_full_size_sdxl_plans_properties():
     out = torch.empty(total, dtype=torch.float32, device="cuda")
     offs = torch.tensor(lay.offsets, device="cuda")
     nums = torch.tensor(lay.numels, device="cuda")
-    ends = offs + nums
 
-    def per_key_sum(x):                                             # fp64 sums per key, in chunks (x: an arena-sized fp32 tensor)
-        acc = torch.zeros(n, dtype=torch.float64, device="cuda")
-        step = 1 << 27
-        for i in range(0, total, step):
-            j = min(i + step, total)
-            pos = torch.arange(i, j, device="cuda")
-            kid = torch.searchsorted(offs, pos, right=True) - 1     # the key that starts at or before the element
-            inside = pos < ends[kid]                                # gaps between keys are dropped
-            acc.index_add_(0, kid, torch.where(inside, x[i:j].double(), torch.zeros((), dtype=torch.float64, device="cuda")))
+    def per_key_sum(*xs):                                           # fp64 sum of the product of the arena-sized tensors, per key
+        acc = torch.empty(n, dtype=torch.float64, device="cuda")
+        for s_, (o, m) in enumerate(zip(lay.offsets, lay.numels)):   # (index_add_ into 2 531 slots serialises on its atomics)
+            v = xs[0][o:o + m].double()
+            for x in xs[1:]:
+                v = v * x[o:o + m].double()
+            acc[s_] = v.sum()
         return acc
 
     # ---- slerp
@@ -238,9 +235,9 @@ def test_full_size_sdxl_plans_properties():
                                      total, _lib.BF16, _lib.F32, 0.3, ws.data_ptr(), ws.numel(), flags.data_ptr(), _stream()), "slerp")
     torch.cuda.synchronize()
     assert int(flags.sum().item()) == 0
-    na = per_key_sum(arenas[0].float() ** 2).sqrt()
-    nb = per_key_sum(arenas[1].float() ** 2).sqrt()
-    no = per_key_sum(out * out).sqrt()
+    na = per_key_sum(arenas[0], arenas[0]).sqrt()
+    nb = per_key_sum(arenas[1], arenas[1]).sqrt()
+    no = per_key_sum(out, out).sqrt()
     want = na + 0.3 * (nb - na)
     big = nums >= 64                                                # tiny keys (n = 1 .. 4 scalars) can be anti-parallel: omega ~ pi is ill-conditioned
     rel = ((no - want).abs() / want)[big]
@@ -261,9 +258,9 @@ def test_full_size_sdxl_plans_properties():
     assert int(flags.sum().item()) == 0
     x = arenas[0].float() - arenas[2].float()
     perp = out - arenas[0].float()
-    dot = per_key_sum(perp * x)
-    nx2 = per_key_sum(x * x)
-    np2 = per_key_sum(perp * perp)
+    dot = per_key_sum(perp, x)
+    nx2 = per_key_sum(x, x)
+    np2 = per_key_sum(perp, perp)
     cosine = (dot.abs() / (nx2.sqrt() * np2.sqrt()).clamp_(min=1e-30))[big]
     assert float(cosine.max()) < 1e-4, float(cosine.max())         # fp32 rounding of a + perp, then perp recovered by subtraction
     for s in [1, n // 2] + list(rng.integers(0, n, size=4)):

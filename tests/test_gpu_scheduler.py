@@ -58,10 +58,12 @@ def test_generic_path_runs_method_bodies_per_key(toy_models):               # no
     a, b = (safetensors.torch.load_file(str(p)) for p in toy_models[:2])
     for k in SHAPES:
         assert torch.equal(res[k], (2 * a[k].float() - b[k].float()).to(torch.bfloat16)), k
-    # slerp through merge(): generic path, vs the per-key call
+    # slerp through merge() (a batched plan since round 3) vs the per-key call: the same fp64 sums in another order
+    from conftest import ulp_distance_half
     res = amd.merge(amd.slerp(m[0], m[1], alpha=0.3), **kw)
     want = amd.slerp(a["w.linear"].cuda(), b["w.linear"].cuda(), 0.3, out_dtype=torch.bfloat16).cpu()
-    assert torch.equal(res["w.linear"], want)
+    bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16).reshape(-1)      # noqa: E731
+    assert ulp_distance_half(bits(res["w.linear"]), bits(want)).max() <= 1
 
 
 def test_pipeline_many_waves_medium_checkpoint(tmp_path):

@@ -150,7 +150,8 @@ def test_fuser_recognises_the_benchmark_recipes(toy_models):
     assert t.kind == "ties" and t.models == m and t.params == {"k": 0.2, "alpha": 1.0, "vote_sgn": False} and t.fallback is m[0]
     assert fuse(m[0] + amd.ties_sum(*deltas, k=0.2)).kind == "ties"                     # operator sugar: + is add_difference
     assert fuse(amd.add_difference(m[0], amd.ties_sum(amd.subtract(m[1], m[2]), k=0.2))) is None   # delta not against the base
-    assert fuse(amd.slerp(m[0], m[1])) is None                                          # generic per-key path
+    assert fuse(amd.slerp(m[0], m[1])).kind == "slerp"                                  # round 3: a batched plan of its own
+    assert fuse(amd.slerp(m[0], amd.subtract(m[1], m[2]))) is None                      # generic per-key path
     text = amd.serialize(amd.add_difference(m[0], amd.ties_sum(*deltas, k=0.2), alpha=1.0))
     assert text.splitlines()[0] == "version 0.1.0" and 'merge "ties_sum"' in text and 'merge "add_difference" &0' in text
 
@@ -190,7 +191,7 @@ def plan_recipes(amd, pm):
         "dare_nostock": (amd.add_difference(ms[0], amd.ties_sum_with_dropout(*deltas, apply_stock=True, seed=114514, probability=0.4, k=0.5), alpha=1.0), "dare"),
         "dare_nostock_norescale": (amd.add_difference(ms[0], amd.ties_sum_with_dropout(*deltas, apply_stock=True, seed=7, probability=0.9, k=1.0, rescale=False), alpha=1.0), "dare"),
         "dare_default_seed": (amd.add_difference(ms[0], amd.ties_sum_with_dropout(*deltas, apply_stock=True, probability=0.5, k=0.2), alpha=1.0), "dare"),
-        "dare_stock": (amd.add_difference(ss[0], amd.ties_sum_with_dropout(*sdeltas, seed=3, probability=0.4, k=0.5), alpha=0.8), "dare_stock"),
+        "dare_stock": (amd.add_difference(ss[0], amd.ties_sum_with_dropout(*sdeltas, seed=3, probability=0.4, k=0.5), alpha=0.8), "dare"),
     }
 
 
@@ -210,7 +211,7 @@ PLAN_EXACT = {"addsub", "adddiff"}            # one fma per element: bit for bit
 
 
 @pytest.mark.parametrize("name", ["slerp", "slerp_zero", "slerp_nonfinite", "addperp", "addperp_zero", "addsub", "adddiff", "dare_nostock",
-                                  "dare_nostock_norescale", "dare_default_seed"])
+                                  "dare_nostock_norescale", "dare_default_seed", "dare_stock"])
 @pytest.mark.parametrize("buffer", [1 << 31, 1 << 16])
 def test_round3_plans_reproduce_reference_cpu(plan_models, name, buffer, tmp_path):
     """merge() on the batched plans of round 3 against the reference's own sd_mecha.merge outputs (tests/golden/e2e_plans.npz),
@@ -223,7 +224,7 @@ def test_round3_plans_reproduce_reference_cpu(plan_models, name, buffer, tmp_pat
     assert plan is not None and plan.kind == kind
     res = amd.merge(recipe, backend=OracleBackend(), merge_device="cpu", output_dtype=torch.bfloat16, total_buffer_size=buffer, threads=0)
     check_plan_result(res, name, 0 if name in PLAN_EXACT else 1)
-    assert merging.last_stats["generic_keys"] == 0 and merging.last_stats["fused_keys"] == 4
+    assert merging.last_stats["generic_keys"] == 0 and merging.last_stats["fused_keys"] == (3 if name == "dare_stock" else 4)
 
 
 # ------------------------------------------------------------------ .mecha text (row f1)
