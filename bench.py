@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sdxl_ties", choices=sorted(WORKLOADS))
+    ap.add_argument("--inputs", default="random", choices=["random", "finetune"],
+                    help="random: independent N(0, 0.02^2) checkpoints (SURVEY.md 8d).  finetune: model i = bf16(base + delta_i), delta_i ~ N(0, 0.001^2) "
+                         "with 30 / 50 / 70 ... %% of its elements exactly zero: what TIES is run on in practice (few distinct |delta| levels, masses of ties and zeros)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU baseline sample")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end merge() leg (files on tmpfs -> file)")
@@ -89,7 +92,7 @@ def parse_args():
 class Job:
     """One rank's stripe: arenas in HBM + the launch sequence of one step."""
 
-    def __init__(self, workload: str, rank: int, device):
+    def __init__(self, workload: str, rank: int, device, inputs: str = "random"):
         manifest, comps, n_models, recipe, shards = WORKLOADS[workload]
         self.manifest = load_manifest(manifest, comps)
         items = [(k, numel(s)) for k, s, _ in self.manifest]
@@ -102,9 +105,18 @@ class Job:
         L = self.layout
         gen = torch.Generator(device=device).manual_seed(1234 + rank)
         self.arenas = []
-        for _ in range(n_models):
+        for m in range(n_models):
             a = torch.empty(L.total_elems, dtype=torch.bfloat16, device=device)
             a.normal_(0.0, 0.02, generator=gen)            # random-init weights, N(0, 0.02^2)
+            if inputs == "finetune" and m > 0:
+                # a fine-tune of model 0: small deltas, a share of them exactly zero, rounded to the storage dtype with the weight
+                zero_frac = (0.3, 0.5, 0.7)[(m - 1) % 3]
+                step = 1 << 27
+                for i in range(0, L.total_elems, step):
+                    j = min(i + step, L.total_elems)
+                    delta = torch.randn(j - i, device=device, generator=gen) * 0.001
+                    delta *= (torch.rand(j - i, device=device, generator=gen) >= zero_frac)
+                    a[i:j] = (self.arenas[0][i:j].float() + delta).to(torch.bfloat16)
             self.arenas.append(a)
         self.out = torch.zeros(L.total_elems, dtype=torch.bfloat16, device=device)
         self.segs_host = L.host_segments()
@@ -388,7 +400,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
 
-    job = Job(args.workload, rank, device)
+    job = Job(args.workload, rank, device, args.inputs)
     for _ in range(args.warmup):
         job.step()
 
@@ -449,7 +461,7 @@ def main():
             "value_is": "hbm_resident_loop", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "description": DESCRIPTION[args.workload], "keys": len(job.layout.keys),
+            "config": {"workload": args.workload, "inputs": args.inputs, "description": DESCRIPTION[args.workload], "keys": len(job.layout.keys),
                        "elements_per_rank": elems, "bytes_per_step_per_rank": job.payload_bytes,
                        "storage_dtype": "bf16 in / bf16 out", "parallelism": f"key stripes x{world}, no collective"},
             "hbm_frac_whole_step": round(value / world / HBM_PEAK_GBS, 4),

@@ -369,74 +369,200 @@ __device__ __forceinline__ void bred_operands(const BredParams &p, int64_t e, in
     }
 }
 
-// Two tiles per block: with two input streams one vector position per thread keeps only 32 bytes per lane in flight (4.7 TB/s
-// on the SDXL x2 job; a read-only pass with 64 bytes per lane reaches 7).  Both tiles' loads are issued before either is reduced.
-constexpr int BRED_U = 2;
-template <int MODE, int IN_DT>
-__global__ __launch_bounds__(MECHA_BLOCK) void bred_reduce_kernel(BredParams p) {
-    const int local = threadIdx.x * 8;
-    BredTile rec[BRED_U];
-    int valid[BRED_U];
-    float x[BRED_U][8], y[BRED_U][8], a0[8];
-    bool bad_in[BRED_U];
+// The reduce pass as a walk: a block owns a contiguous run of `chunk` tiles and every lane keeps fp64 partial sums for the key it
+// is in; they are folded across the wave and written ONCE per (block, key) -- into the slots of the key's first tile inside the
+// block's run -- instead of once per tile.  (A fold per tile costs 36 ds_bpermute per wave for three doubles: the flat
+// one-block-per-tile form ran at one tile per 1.7 ns whatever it read -- 3.0 ms for 13.9 GB as for 20.8 GB -- bound by the LDS
+// crossbar, not by HBM.)  The loads of tile t + 1 are issued before tile t is consumed (two register slots of raw words,
+// converted when consumed).  Which slots hold a partial follows from `chunk` alone, so the finish pass finds them without a
+// list, and the sums do not depend on the order the blocks run in.
+constexpr int BRED_WAVES = MECHA_BLOCK / 64;      // partial slots per tile (one per wave)
+
+template <int IN_DT> struct BredRaw { u32x4 w[IN_DT == MECHA_F32 ? 2 : 1]; };
+template <int IN_DT>
+__device__ __forceinline__ BredRaw<IN_DT> bred_load_raw(const void *ptr, int64_t e, int valid, bool vec) {
+    BredRaw<IN_DT> r;
+    if (vec) {
+        if constexpr (IN_DT == MECHA_F32) {
+            const u32x4 *q = reinterpret_cast<const u32x4 *>(reinterpret_cast<const float *>(ptr) + e);
+            r.w[0] = __builtin_nontemporal_load(q);
+            r.w[1] = __builtin_nontemporal_load(q + 1);
+        } else {
+            r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(ptr) + e));
+        }
+    } else {
+        uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < BRED_U; u++) {
-        const long long t = (long long)blockIdx.x * BRED_U + u;
-        rec[u] = (t < p.n_tiles) ? p.tiles[t] : BredTile{0, 0, 0};
-        valid[u] = rec[u].valid - local >= 8 ? 8 : (rec[u].valid - local > 0 ? rec[u].valid - local : 0);
-        bad_in[u] = false;
-    }
-#pragma unroll
-    for (int u = 0; u < BRED_U; u++)
-        if (valid[u] > 0) bred_operands<MODE, IN_DT>(p, rec[u].elem + local, valid[u], p.vec_ok && valid[u] == 8, x[u], y[u], a0, bad_in[u]);
-    __shared__ double wsum[MECHA_BLOCK / 64][BRED_U][3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int u = 0; u < BRED_U; u++) {
-        // A lane's 8 elements are summed in fp32, in index order (three fp64 fmas and two conversions per element made this pass
-        // VALU-bound: 4.5 TB/s); everything above a lane -- the wave, the block, the key's tiles -- is summed in fp64.  The fp32
-        // part rounds at 2^-24 of a lane's own partial sum; torch's own reduction is an fp32 cascade throughout.
-        float fxx = 0.0f, fyy = 0.0f, fxy = 0.0f;
-        if (valid[u] > 0) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                fxx = __builtin_fmaf(x[u][j], x[u][j], fxx);
-                fyy = __builtin_fmaf(y[u][j], y[u][j], fyy);
-                fxy = __builtin_fmaf(x[u][j], y[u][j], fxy);
+        for (int j = 0; j < 8; j++) {
+            if (j < valid) {
+                if constexpr (IN_DT == MECHA_F32) t[j] = reinterpret_cast<const uint32_t *>(ptr)[e + j];
+                else t[j >> 1] |= (uint32_t)reinterpret_cast<const uint16_t *>(ptr)[e + j] << (16 * (j & 1));
             }
         }
-        double sxx = fxx, syy = fyy, sxy = fxy;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            sxx += __shfl_down(sxx, off, 64);
-            syy += __shfl_down(syy, off, 64);
-            sxy += __shfl_down(sxy, off, 64);
-        }
-        if (lane == 0) { wsum[wave][u][0] = sxx; wsum[wave][u][1] = syy; wsum[wave][u][2] = sxy; }
-        if (bad_in[u] && p.flags != nullptr) atomicOr(p.flags + rec[u].seg, MECHA_FLAG_INPUT_NONFINITE);
+        r.w[0] = u32x4{t[0], t[1], t[2], t[3]};
+        if constexpr (IN_DT == MECHA_F32) r.w[1] = u32x4{t[4], t[5], t[6], t[7]};
     }
-    __syncthreads();
-    if (threadIdx.x < 3 * BRED_U) {
-        const int u = threadIdx.x / 3, c = threadIdx.x % 3;
-        const long long t = (long long)blockIdx.x * BRED_U + u;
-        if (t < p.n_tiles) {
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < MECHA_BLOCK / 64; w++) tot += wsum[w][u][c];
-            p.partial[t * 3 + c] = tot;
-        }
+    return r;
+}
+template <int IN_DT>
+__device__ __forceinline__ void bred_unpack(const BredRaw<IN_DT> &r, float (&v)[8]) {
+    if constexpr (IN_DT == MECHA_F32) {
+        v[0] = __uint_as_float(r.w[0].x); v[1] = __uint_as_float(r.w[0].y); v[2] = __uint_as_float(r.w[0].z); v[3] = __uint_as_float(r.w[0].w);
+        v[4] = __uint_as_float(r.w[1].x); v[5] = __uint_as_float(r.w[1].y); v[6] = __uint_as_float(r.w[1].z); v[7] = __uint_as_float(r.w[1].w);
+    } else {
+        unpack16<IN_DT>(r.w[0], v);
     }
 }
 
+template <int MODE, int IN_DT>
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_reduce_kernel(BredParams p, long long chunk) {
+    const long long t0 = (long long)blockIdx.x * chunk;
+    const long long t1 = (t0 + chunk < p.n_tiles) ? t0 + chunk : p.n_tiles;
+    if (t0 >= t1) return;
+    const int local = threadIdx.x * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NIN = MODE == RM_ADDPERP ? 3 : 2;
+    BredTile rec_u[2];
+    int valid_u[2];
+    BredRaw<IN_DT> raw_u[2][NIN];
+    auto issue = [&](long long t, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const BredTile rec = p.tiles[t];
+        const int valid = rec.valid - local >= 8 ? 8 : (rec.valid - local > 0 ? rec.valid - local : 0);
+        rec_u[slot] = rec;
+        valid_u[slot] = valid;
+        if (valid == 0) return;
+        const bool vec = p.vec_ok && valid == 8;
+        const int64_t e = rec.elem + local;
+        raw_u[slot][0] = bred_load_raw<IN_DT>(p.a, e, valid, vec);
+        raw_u[slot][1] = bred_load_raw<IN_DT>(p.b, e, valid, vec);
+        if constexpr (MODE == RM_ADDPERP) raw_u[slot][2] = bred_load_raw<IN_DT>(p.c, e, valid, vec);
+    };
+    double axx = 0.0, ayy = 0.0, axy = 0.0;          // this lane's sums over the current key's tiles of this block
+    f32x2 poison = {0.0f, 0.0f};                     // fma(v, 0, poison): 0 while every input is finite, NaN after an inf / NaN
+    int cur_seg = -1;
+    long long run_first = t0;                        // the tile whose slots receive the current key's partials
+    auto flush = [&]() {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            axx += __shfl_down(axx, off, 64);
+            ayy += __shfl_down(ayy, off, 64);
+            axy += __shfl_down(axy, off, 64);
+        }
+        if (lane == 0) {
+            double *dst = p.partial + (run_first * BRED_WAVES + wave) * 3;
+            dst[0] = axx; dst[1] = ayy; dst[2] = axy;
+        }
+        if (((poison.x != poison.x) | (poison.y != poison.y)) && p.flags != nullptr) atomicOr(p.flags + cur_seg, MECHA_FLAG_INPUT_NONFINITE);
+        axx = ayy = axy = 0.0;
+        poison = f32x2{0.0f, 0.0f};
+    };
+    auto consume = [&](long long t, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const int seg = rec_u[slot].seg;             // block-uniform
+        if (seg != cur_seg) {
+            if (cur_seg >= 0) flush();
+            cur_seg = seg;
+            run_first = t;
+        }
+        if (valid_u[slot] == 0) return;
+        float x[8], y[8];
+        bred_unpack<IN_DT>(raw_u[slot][0], x);
+        bred_unpack<IN_DT>(raw_u[slot][1], y);
+        const f32x2 zero2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            poison = __builtin_elementwise_fma(f32x2{x[j], x[j + 1]}, zero2, poison);
+            poison = __builtin_elementwise_fma(f32x2{y[j], y[j + 1]}, zero2, poison);
+        }
+        if constexpr (MODE == RM_ADDPERP) {
+            float c[8];
+            bred_unpack<IN_DT>(raw_u[slot][2], c);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) poison = __builtin_elementwise_fma(f32x2{c[j], c[j + 1]}, zero2, poison);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { x[j] = x[j] - c[j]; y[j] = y[j] - c[j]; }          // subtract (linear.py:101)
+        }
+        // a lane's 8 elements in fp32, in index order (products of 16-bit values are exact); everything above that in fp64.  The fp32
+        // part rounds at 2^-24 of those 8 elements' own sum; torch's reduction is an fp32 cascade throughout.
+        float fxx = 0.0f, fyy = 0.0f, fxy = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            fxx = __builtin_fmaf(x[j], x[j], fxx);
+            fyy = __builtin_fmaf(y[j], y[j], fyy);
+            fxy = __builtin_fmaf(x[j], y[j], fxy);
+        }
+        axx += (double)fxx; ayy += (double)fyy; axy += (double)fxy;
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    issue(t0, S0{});
+    for (long long t = t0; t < t1; t += 2) {
+        if (t + 1 < t1) issue(t + 1, S1{});
+        consume(t, S0{});
+        if (t + 2 < t1) issue(t + 2, S0{});
+        if (t + 1 < t1) consume(t + 1, S1{});
+    }
+    flush();
+}
+
+// The flat form of the same pass (one block per tile, every wave writes its own partial; chunk = 1 for the finish pass): with
+// THREE input streams a tile carries enough bytes per fold that the walk's looped loads lose more (4.0 ms) than the folds cost
+// (3.3 ms for the 20.8 GB of the SDXL x3 job = 6.3 TB/s); with two streams it is the other way round (3.0 against 2.3 ms).
+template <int MODE, int IN_DT>
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_reduce_flat_kernel(BredParams p) {
+    const BredTile rec = p.tiles[blockIdx.x];
+    const int local = threadIdx.x * 8;
+    const int valid = rec.valid - local >= 8 ? 8 : (rec.valid - local > 0 ? rec.valid - local : 0);
+    float fxx = 0.0f, fyy = 0.0f, fxy = 0.0f;
+    bool bad_in = false;
+    if (valid > 0) {
+        float x[8], y[8], a0[8];
+        bred_operands<MODE, IN_DT>(p, rec.elem + local, valid, p.vec_ok && valid == 8, x, y, a0, bad_in);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            fxx = __builtin_fmaf(x[j], x[j], fxx);
+            fyy = __builtin_fmaf(y[j], y[j], fyy);
+            fxy = __builtin_fmaf(x[j], y[j], fxy);
+        }
+    }
+    double sxx = fxx, syy = fyy, sxy = fxy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sxx += __shfl_down(sxx, off, 64);
+        syy += __shfl_down(syy, off, 64);
+        sxy += __shfl_down(sxy, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        double *dst = p.partial + ((long long)blockIdx.x * BRED_WAVES + (threadIdx.x >> 6)) * 3;
+        dst[0] = sxx; dst[1] = syy; dst[2] = sxy;
+    }
+    if (bad_in && p.flags != nullptr) atomicOr(p.flags + rec.seg, MECHA_FLAG_INPUT_NONFINITE);
+}
+
 template <int MODE>
-__global__ __launch_bounds__(64) void bred_finish_kernel(BredParams p) {
+__global__ __launch_bounds__(MECHA_BLOCK) void bred_finish_kernel(BredParams p, long long chunk) {
     const int s = blockIdx.x;
-    const long long t0 = p.tile_start[s], t1 = p.tile_start[s + 1];
+    // the key's partials sit at its first tile and at every multiple of `chunk` inside it (where another block took over)
+    const long long first = p.tile_start[s], end = p.tile_start[s + 1];
+    const long long k0 = first / chunk + 1;                                   // first block boundary strictly after `first`
+    const long long k1 = (end - 1) / chunk;                                   // last block boundary before `end`
+    const long long n_runs = 1 + (k1 >= k0 ? k1 - k0 + 1 : 0);
     double s0 = 0, s1 = 0, s2 = 0;
-    for (long long t = t0 + threadIdx.x; t < t1; t += 64) { s0 += p.partial[t * 3]; s1 += p.partial[t * 3 + 1]; s2 += p.partial[t * 3 + 2]; }
+    for (long long i = threadIdx.x; i < n_runs * BRED_WAVES; i += MECHA_BLOCK) {
+        const long long run = i / BRED_WAVES;
+        const long long t = run == 0 ? first : (k0 + run - 1) * chunk;
+        const double *src = p.partial + (t * BRED_WAVES + i % BRED_WAVES) * 3;
+        s0 += src[0]; s1 += src[1]; s2 += src[2];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    __shared__ double wsum[MECHA_BLOCK / 64][3];
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6][0] = s0; wsum[threadIdx.x >> 6][1] = s1; wsum[threadIdx.x >> 6][2] = s2; }
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    s0 = s1 = s2 = 0;
+    for (int w = 0; w < MECHA_BLOCK / 64; w++) { s0 += wsum[w][0]; s1 += wsum[w][1]; s2 += wsum[w][2]; }
     RedScalars sc{};
     sc.na = (float)__builtin_sqrt(s0);
     sc.nb = (float)__builtin_sqrt(s1);
@@ -593,7 +719,7 @@ BredLayout bred_layout(int n_segs, int64_t total_elems) {
     size_t off = 0;
     w.tile_start_off = off; off = bred_align(off + sizeof(long long) * ((size_t)n_segs + 1));
     w.tiles_off = off;      off = bred_align(off + sizeof(BredTile) * w.max_tiles);
-    w.partial_off = off;    off = bred_align(off + sizeof(double) * 3 * w.max_tiles);
+    w.partial_off = off;    off = bred_align(off + sizeof(double) * 3 * BRED_WAVES * w.max_tiles);
     w.sc_off = off;         off = bred_align(off + sizeof(RedScalars) * (size_t)n_segs);
     w.globals_off = off;    off = bred_align(off + sizeof(BredGlobals));
     w.nan_keys_off = off;   off = bred_align(off + sizeof(int) * (size_t)n_segs);
@@ -641,10 +767,14 @@ int run_batched_reduce(const void *a, const void *b, const void *c, void *out, c
     MECHA_LAUNCH(MK_TIES_INDEX, bred_tile_records_kernel, dim3((unsigned)n_segs), dim3(MECHA_BLOCK), 0, s, segs_dev, p.tile_start,
                  reinterpret_cast<BredTile *>(ws + w.tiles_off));
     const unsigned grid = (unsigned)n_tiles;
+    // the reduce pass: 8 resident blocks per CU, each with a contiguous run of tiles
+    const long long chunk = MODE == RM_ADDPERP ? 1 : (n_tiles + MECHA_MAX_GRID - 1) / MECHA_MAX_GRID;
+    const unsigned red_grid = (unsigned)((n_tiles + chunk - 1) / chunk);
     const unsigned fix_grid = (unsigned)(n_tiles < 2048 ? n_tiles : 2048);
     MECHA_DISPATCH_DTYPES(in_dt, out_dt, {
-        MECHA_LAUNCH(MK_RED_REDUCE, (bred_reduce_kernel<MODE, IN_DT>), dim3((grid + BRED_U - 1) / BRED_U), dim3(MECHA_BLOCK), 0, s, p);
-        MECHA_LAUNCH(MK_RED_FINISH, (bred_finish_kernel<MODE>), dim3((unsigned)n_segs), dim3(64), 0, s, p);
+        if constexpr (MODE == RM_ADDPERP) MECHA_LAUNCH(MK_RED_REDUCE, (bred_reduce_flat_kernel<MODE, IN_DT>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p);
+        else MECHA_LAUNCH(MK_RED_REDUCE, (bred_reduce_kernel<MODE, IN_DT>), dim3(red_grid), dim3(MECHA_BLOCK), 0, s, p, chunk);
+        MECHA_LAUNCH(MK_RED_FINISH, (bred_finish_kernel<MODE>), dim3((unsigned)n_segs), dim3(MECHA_BLOCK), 0, s, p, chunk);
         MECHA_LAUNCH(MK_RED_APPLY, (bred_apply_kernel<MODE, IN_DT, OUT_DT>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p);
         MECHA_LAUNCH(MK_RED_FIXUP, (bred_fixup_kernel<MODE, IN_DT, OUT_DT>), dim3(fix_grid), dim3(MECHA_BLOCK), 0, s, p);
         MECHA_LAUNCH(MK_RED_FIXUP, bred_flags_kernel, dim3((unsigned)((n_segs + MECHA_BLOCK - 1) / MECHA_BLOCK)), dim3(MECHA_BLOCK), 0, s, p);

@@ -58,7 +58,7 @@ struct SelectState {                       // per (key, delta), 64 bytes
     unsigned long long amb_offset;         // A: first slot of this pair's ambiguous list
 };
 struct SelectCounts { unsigned long long below, eq_lo; };
-struct TiesGlobals { uint32_t n_failed; uint32_t pad; unsigned long long n_amb; unsigned long long n_hit; };
+struct TiesGlobals { uint32_t n_failed; uint32_t n_pending; unsigned long long n_amb; unsigned long long n_hit; };
 
 struct TileRec { long long elem; int seg; int valid; };     // first element of the tile inside the arena, its key, its element count
 
@@ -68,6 +68,7 @@ struct TiesParams {
     const uint32_t *keep_bits;             // DARE masks or nullptr
     int64_t mask_words;                    // words per delta row of keep_bits (row form)
     int mask_stream;                       // 1: keep_bits is ONE Bernoulli stream; delta m of a key of n elements uses bits [m n, (m + 1) n)
+    int presolved;                         // 1: ties_dare_presolve_kernel ran: pairs it settled (threshold 0) are MODE_RESOLVED, the others MODE_PENDING
     int n_deltas;
     int in_dt, out_dt;
     int raw;                               // model_stock (ties.py:137-143): the stock kernels take the deltas as they are
@@ -572,6 +573,7 @@ template <int PASS, int CAP, bool DARE>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, int d0, int nd) {
     using C = PassCfg<PASS>;
     if (p.bracket && p.globals->n_failed == 0) return;             // nothing fell back
+    if (p.presolved && p.globals->n_pending == 0) return;          // DARE: every pair was settled from its mask
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * TIES_BINS words
     for (int i = threadIdx.x; i < nd * TIES_BINS; i += MECHA_BLOCK) lds_hist[i] = 0;
     __syncthreads();
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
                 if (d < nd) {
                     const SelectState &st = p.state[(int64_t)cur.s * p.n_deltas + d0 + d];
                     // pipeline A: only the pairs whose bracket missed; pipeline B: every pair (pass 1), then those pass 1 did not settle
-                    active[d] = p.bracket ? st.mode == MODE_FAILED : (PASS == 1 || st.mode != MODE_RESOLVED);
+                    active[d] = p.bracket ? st.mode == MODE_FAILED : ((PASS == 1 && !p.presolved) || st.mode != MODE_RESOLVED);
                     if constexpr (PASS > 1) want[d] = st.prefix;
                 }
             }
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_hist_kernel(TiesParams p, in
         bool any = false;
 #pragma unroll
         for (int d = 0; d < CAP; d++) any |= (d < nd) && active[d];
-        if (!any) continue;
+        if (!any) { t = cur.end - 1; continue; }                     // nothing to find in this key: on to the next one
         const mecha_segment seg = cur.seg;
 #pragma unroll 1
         for (int u = 0; u < 2; u++) {
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_scan_kernel(TiesParams p, do
     __shared__ unsigned long long sel_below;
     __shared__ uint32_t sel_count;
     if (p.bracket && p.globals->n_failed == 0) return;
+    if (p.presolved && p.globals->n_pending == 0) return;
     const int64_t sd = blockIdx.x;
     const int s = (int)(sd / p.n_deltas);
     uint32_t *h = p.hist + sd * TIES_BINS;
@@ -690,6 +693,8 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_scan_kernel(TiesParams p, do
     if (p.bracket && st.mode != MODE_FAILED) return;
     if constexpr (PASS > 1) {
         if (!p.bracket && st.mode == MODE_RESOLVED) return;                  // settled by pass 1 (its histogram is already clear)
+    } else {
+        if (!p.bracket && p.presolved && st.mode == MODE_RESOLVED) return;   // settled from the masks alone
     }
     if constexpr (PASS == 1) {
         st.kth = ties_kth(one_minus_k, get_segment(p, s).numel);
@@ -724,6 +729,52 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_scan_kernel(TiesParams p, do
     }
 }
 
+// ------------------------------------------------------------------------------------------------ DARE: thresholds from the masks alone
+// A DARE-masked delta holds at least (numel - kept) exact zeros, kept = set bits of its mask.  If the rank kth lies inside them,
+// the kth-smallest |delta * mask| IS 0 (ties.py:33, :128-132) and no pass over the deltas is needed to know it: with the usual
+// settings (probability 0.9, k 0.2 .. 1.0: kth <= 0.8 numel <= dropped) that settles every pair from 1/16 of a byte per element.
+// One block per (key, delta); the pairs it cannot settle go through the radix passes.
+constexpr int64_t PRESOLVE_SLICE_WORDS = 1 << 16;          // mask words per block (2 M elements of one delta)
+// counts[sd].below += set bits of this block's slice of the pair's mask
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_dare_presolve_kernel(TiesParams p) {
+    const int64_t sd = blockIdx.x;
+    const int s = (int)(sd / p.n_deltas), m = (int)(sd % p.n_deltas);
+    const int64_t numel = get_segment(p, s).numel;
+    const int64_t b0 = p.mask_stream ? (int64_t)m * numel : (int64_t)m * p.mask_words * 32, b1 = b0 + numel;    // bit range
+    const int64_t w0 = b0 >> 5, w1 = (b1 + 31) >> 5;
+    const int64_t lo = w0 + (int64_t)blockIdx.y * PRESOLVE_SLICE_WORDS;
+    if (lo >= w1) return;
+    const int64_t hi = lo + PRESOLVE_SLICE_WORDS < w1 ? lo + PRESOLVE_SLICE_WORDS : w1;
+    unsigned long long kept = 0;
+    for (int64_t w = lo + threadIdx.x; w < hi; w += MECHA_BLOCK) {
+        uint32_t word = p.keep_bits[w];
+        if (w == w0) word &= ~0u << (b0 & 31);
+        if (w == w1 - 1 && (b1 & 31)) word &= (1u << (b1 & 31)) - 1u;
+        kept += __popc(word);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off, 64);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&p.counts[sd].below, kept);
+}
+
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_dare_presolve_decide_kernel(TiesParams p, int64_t n_sd, double one_minus_k, float *thresholds_out) {
+    const int64_t sd = (int64_t)blockIdx.x * MECHA_BLOCK + threadIdx.x;
+    if (sd >= n_sd) return;
+    const int64_t numel = get_segment(p, (int)(sd / p.n_deltas)).numel;
+    SelectState st{};
+    st.kth = ties_kth(one_minus_k, numel);
+    st.kth_rem = st.kth;
+    if (st.kth <= (unsigned long long)numel - p.counts[sd].below) {
+        st.mode = MODE_RESOLVED;
+        if (thresholds_out != nullptr) thresholds_out[sd] = 0.0f;
+    } else {
+        st.mode = MODE_PENDING;
+        atomicAdd(&p.globals->n_pending, 1u);
+    }
+    p.counts[sd].below = 0;
+    p.state[sd] = st;
+}
+
 // ------------------------------------------------------------------------------------------------ merge
 struct MergeExtra {
     float alpha;            // add_difference weight (base mode)
@@ -731,6 +782,9 @@ struct MergeExtra {
     int vote_sgn;
     int has_rescale;
     int skip_full_tiles;    // 1: ties_merge_full_kernel runs too and owns the full tiles of the keys it accepts
+    int full_any_thr;       // 1: ... of EVERY key (its DARE form needs no threshold >= 2^-90)
+    float rescale_rcp;      // RN(1 / rescale_div)
+    int fast_rescale;       // the three-instruction division by rescale_div is safe (a normal divisor, significand not all ones)
 };
 
 __device__ __forceinline__ float sign_f(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }   // torch.sign: sign(+-0) = 0
@@ -805,7 +859,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_kernel(TiesParams p, M
         const mecha_segment seg = cur.seg;
         // the same test as in ties_merge_full_kernel: that kernel merges every full tile of this key.  Only the key's last tile can
         // be ragged: the walk jumps to it (or past the key) instead of visiting 400 full tiles per block one by one
-        if (x.skip_full_tiles && in_regs && fast_div) {
+        if (x.skip_full_tiles && in_regs && (fast_div || x.full_any_thr)) {
             const long long last = cur.end - 1;
             const bool last_ragged = (cur.end - cur.first) * TIES_TILE > seg.numel;
             if (t < last || !last_ragged) { t = (last_ragged ? last : cur.end) - 1; continue; }
@@ -1037,7 +1091,10 @@ __device__ __forceinline__ int sign_i32(int v) {
 // scheduler hoists every model's unpack and subtraction to the front; half the elements is half the registers.
 // (5 waves per SIMD by launch bounds -- 96 VGPRs, 2 spilled with 3 models, 11 with 7 -- measured slower: 5.9 against 5.5 ms
 //  on the SDXL x4 job, 6.7 against 4.7 on the FLUX stripe)
-template <int N, int DT, int ODT, int E>
+// DARE: the same with the keep masks of ties_sum_with_dropout (delta * mask before the filter, ties.py:33; the result divided by
+// 1 - probability, ties.py:50).  A masked delta is mostly zeros, so thresholds are usually 0 and kept values may be anything:
+// -0 is normalised before the sign is taken, and a sum in the denormal range sends its vector through the IEEE divisions.
+template <int N, int DT, int ODT, int E, bool DARE>
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams p, MergeExtra x, void *out, uint32_t *flags) {
     constexpr int P = E / 2;                       // pairs per lane
     constexpr int BLOCKS_PER_TILE = TIES_TILE / (MECHA_BLOCK * E);
@@ -1075,7 +1132,20 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
             any_amb = any_amb || (amb_hi[d] >= 0.0f);
         }
     }
-    if (!key_ok) return;                                                                // ties_merge_kernel's key (same test there)
+    if (!DARE && !key_ok) return;                                                       // ties_merge_kernel's key (same test there)
+    uint32_t mbits[N];                                                                  // DARE: this lane's E keep bits per model
+    if constexpr (DARE) {
+        const mecha_segment seg = p.tile_rec != nullptr ? p.segs[rec.seg] : p.seg0;
+        const int64_t local = e - seg.offset;
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int64_t sbit = (p.mask_stream ? (int64_t)m * seg.numel : (int64_t)m * p.mask_words * 32) + local;
+            const uint32_t sh = (uint32_t)(sbit & 31);
+            uint32_t w = p.keep_bits[sbit >> 5] >> sh;
+            if (sh > 32u - E) w |= p.keep_bits[(sbit >> 5) + 1] << (32u - sh);
+            mbits[m] = w;
+        }
+    }
     __syncthreads();                                                                    // recip[]
     const f32x2 zero2 = {0.0f, 0.0f};
     const f32x2 alpha2 = {x.alpha, x.alpha};
@@ -1111,7 +1181,10 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
 #pragma unroll
                     for (int j = 0; j < E; j++) {
                         const float d = v2[j >> 1][j & 1];
-                        const bool keep = __builtin_fabsf(d) >= thr[m];                    // filter_top_k (ties.py:128-132)
+                        bool keep = __builtin_fabsf(d) >= thr[m];                          // filter_top_k (ties.py:128-132)
+                        // DARE: delta * mask (ties.py:33), and thresholds may be 0: zeros (dropped, or genuine +-0) pass the filter but
+                        // neither vote nor count where a sign is elected -- they stay out of `kept`, and -0 never reaches sign_i32
+                        if constexpr (DARE) keep = keep && ((mbits[m] >> j) & 1u) && d != 0.0f;
                         kept[j] += keep ? 1 : 0;
                         f[m][j] = keep ? d : 0.0f;
                         sgn[m][j] = sign_i32(__float_as_int(f[m][j]));
@@ -1154,7 +1227,8 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
 #pragma unroll
                     for (int j = 0; j < E; j++) {
                         const float d = v2[j >> 1][j & 1];
-                        const bool keep = __builtin_fabsf(d) >= thr[m];
+                        bool keep = __builtin_fabsf(d) >= thr[m];
+                        if constexpr (DARE) keep = keep && ((mbits[m] >> j) & 1u) && d != 0.0f;
                         kept[j] += keep ? 1 : 0;
                         vote[j] += sign_i32(__float_as_int(keep ? d : 0.0f));
                     }
@@ -1179,7 +1253,8 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                         for (int h = 0; h < 2; h++) {
                             const float d = v2[q][h];
                             // kept and of the elected sign (elected 0: only a zero delta could match, and that one is not kept)
-                            const bool agree = (__builtin_fabsf(d) >= thr[m]) & (sign_i32(__float_as_int(d)) == fs[2 * q + h]);
+                            bool agree = (__builtin_fabsf(d) >= thr[m]) & (sign_i32(__float_as_int(d)) == fs[2 * q + h]);
+                            if constexpr (DARE) agree = agree && ((mbits[m] >> (2 * q + h)) & 1u) && d != 0.0f;
                             g[h] = agree ? d : 0.0f;
                         }
                         acc[q] = acc[q] + g;
@@ -1195,8 +1270,30 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                 const f32x2 negc = {-(float)cnt[2 * q], -(float)cnt[2 * q + 1]};
                 const f32x2 q0 = acc[q] * y;
                 f32x2 qq = __builtin_elementwise_fma(__builtin_elementwise_fma(negc, q0, acc[q]), y, q0);
+                if constexpr (DARE) {
+                    // with a zero threshold a sum may lie in the denormal range, where the fma form is no longer exact: IEEE division
+                    // then; the result is divided by 1 - probability (ties.py:46-50) the same way
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t ab = __float_as_uint(acc[q][h]) & 0x7fffffffu;
+                        if (ab - 1u < 0x12800000u - 1u) qq[h] = acc[q][h] / (float)cnt[2 * q + h];      // 0 < |a| < 2^-90
+                    }
+                }
                 qq.x = __builtin_amdgcn_class(qq.x, 0x1f8) ? qq.x : 0.0f;              // nan_to_num(nan=0, posinf=0, neginf=0)
                 qq.y = __builtin_amdgcn_class(qq.y, 0x1f8) ? qq.y : 0.0f;
+                if constexpr (DARE) {
+                    if (x.has_rescale) {
+                        const f32x2 rc = {x.rescale_rcp, x.rescale_rcp}, nd = {-x.rescale_div, -x.rescale_div};
+                        const f32x2 s0 = qq * rc;
+                        f32x2 sq = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, s0, qq), rc, s0);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const uint32_t ab = __float_as_uint(qq[h]) & 0x7fffffffu;
+                            if (!x.fast_rescale || (ab - 1u < 0x21800000u - 1u) || ab > 0x5d800000u) sq[h] = qq[h] / x.rescale_div;   // outside [2^-60, 2^60]
+                        }
+                        qq = sq;
+                    }
+                }
                 r2[q] = __builtin_elementwise_fma(qq, alpha2, b2[q]);                  // base.addcmul(ties, alpha)  (linear.py:76)
             }
             f32x2 out_poison = zero2;
@@ -1711,8 +1808,18 @@ void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
 }
 
 template <bool DARE>
-void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float *thresholds_out, hipStream_t s) {
+void launch_radix(const TiesParams &p_in, unsigned grid, double one_minus_k, float *thresholds_out, hipStream_t s, int64_t max_numel = 0) {
+    TiesParams p = p_in;
     const unsigned scan_grid = (unsigned)((int64_t)p.n_segs * p.n_deltas);
+    if constexpr (DARE) {
+        if (!p.bracket) {
+            const int64_t slices = ((max_numel + 31) / 32 + 1 + PRESOLVE_SLICE_WORDS - 1) / PRESOLVE_SLICE_WORDS;
+            MECHA_LAUNCH(MK_TIES_SAMPLE, ties_dare_presolve_kernel, dim3(scan_grid, (unsigned)slices), dim3(MECHA_BLOCK), 0, s, p);
+            MECHA_LAUNCH(MK_TIES_SAMPLE, ties_dare_presolve_decide_kernel, dim3((scan_grid + MECHA_BLOCK - 1) / MECHA_BLOCK), dim3(MECHA_BLOCK), 0, s, p,
+                         (int64_t)scan_grid, one_minus_k, thresholds_out);
+            p.presolved = 1;
+        }
+    }
     launch_hist<1, DARE>(p, grid, s);
     MECHA_LAUNCH(MK_TIES_SCAN, (ties_scan_kernel<1>), dim3(scan_grid), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, thresholds_out);
     launch_hist<2, DARE>(p, grid, s);
@@ -1721,13 +1828,13 @@ void launch_radix(const TiesParams &p, unsigned grid, double one_minus_k, float 
     MECHA_LAUNCH(MK_TIES_SCAN, (ties_scan_kernel<3>), dim3(scan_grid), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, thresholds_out);
 }
 
-template <int N, int DT>
+template <int N, int DT, bool DARE>
 void launch_merge_full(const TiesParams &p, const MergeExtra &x, unsigned /*looped_grid*/, void *out, uint32_t *flags, hipStream_t s) {
     constexpr int E = N <= 4 ? 8 : 4;                             // elements per lane (see the kernel; 4 for three models: 5.6-5.8 against 5.5 ms)
     const unsigned grid = (unsigned)(p.total_tiles * (TIES_TILE / (MECHA_BLOCK * E)));          // flat: one block per 256 x E elements
-    if (p.out_dt == MECHA_BF16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_BF16, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
-    else if (p.out_dt == MECHA_F16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F16, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
-    else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F32, E>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    if (p.out_dt == MECHA_BF16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_BF16, E, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    else if (p.out_dt == MECHA_F16) MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F16, E, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
+    else MECHA_LAUNCH(MK_TIES_MERGE, (ties_merge_full_kernel<N, DT, MECHA_F32, E, DARE>), dim3(grid), dim3(MECHA_BLOCK), 0, s, p, x, out, flags);
 }
 
 template <bool DARE>
@@ -1736,17 +1843,18 @@ void launch_merge(const TiesParams &p, const MergeExtra &x_in, unsigned grid, vo
     MergeExtra x = x_in;
     // the common case goes to ties_merge_full_kernel; ties_merge_kernel then only sees what that kernel leaves (timed as
     // "ties_fixup" so that the per-launch average of "ties_merge" stays that of the full-tile kernel)
-    const bool full = !DARE && p.base != nullptr && !w32 && p.vec_ok && !x.vote_sgn && !x.has_rescale && p.n_deltas <= 8 && out != nullptr &&
+    const bool full = p.base != nullptr && !w32 && p.vec_ok && !x.vote_sgn && (DARE || !x.has_rescale) && p.n_deltas <= 8 && out != nullptr &&
                       mecha_aligned16(out);
     if (full) {
         x.skip_full_tiles = 1;
-#define MECHA_FULL_CASE(N_) case N_: if (p.in_dt == MECHA_BF16) launch_merge_full<N_, MECHA_BF16>(p, x, grid, out, flags, s); \
-                                      else launch_merge_full<N_, MECHA_F16>(p, x, grid, out, flags, s); break;
+        x.full_any_thr = DARE ? 1 : 0;
+#define MECHA_FULL_CASE(N_) case N_: if (p.in_dt == MECHA_BF16) launch_merge_full<N_, MECHA_BF16, DARE>(p, x, grid, out, flags, s); \
+                                      else launch_merge_full<N_, MECHA_F16, DARE>(p, x, grid, out, flags, s); break;
         switch (p.n_deltas) {
             MECHA_FULL_CASE(1) MECHA_FULL_CASE(2) MECHA_FULL_CASE(3) MECHA_FULL_CASE(4)
             MECHA_FULL_CASE(5) MECHA_FULL_CASE(6) MECHA_FULL_CASE(7)
-            default: if (p.in_dt == MECHA_BF16) launch_merge_full<8, MECHA_BF16>(p, x, grid, out, flags, s);
-                     else launch_merge_full<8, MECHA_F16>(p, x, grid, out, flags, s);
+            default: if (p.in_dt == MECHA_BF16) launch_merge_full<8, MECHA_BF16, DARE>(p, x, grid, out, flags, s);
+                     else launch_merge_full<8, MECHA_F16, DARE>(p, x, grid, out, flags, s);
         }
 #undef MECHA_FULL_CASE
     }
@@ -1877,6 +1985,11 @@ int run_ties(const TiesCall &c) {
     x.vote_sgn = c.vote_sgn;
     x.has_rescale = dare && c.rescale;
     x.rescale_div = 1.0f - c.probability;                 // 1.0 - probability as fp32 tensor arithmetic (ties.py:49)
+    x.rescale_rcp = 1.0f / x.rescale_div;
+    {
+        uint32_t rb; memcpy(&rb, &x.rescale_div, 4); rb &= 0x7fffffffu;
+        x.fast_rescale = (rb >= 0x21800000u && rb <= 0x5d800000u && (rb & 0x7fffffu) != 0x7fffffu) ? 1 : 0;
+    }
 
     if (c.model_stock) {
         StockParams sp{};
@@ -1895,7 +2008,7 @@ int run_ties(const TiesCall &c) {
         const int64_t tblocks = (n_rows + MECHA_BLOCK - 1) / MECHA_BLOCK;
         const unsigned tgrid = (unsigned)(tblocks < 65536 ? tblocks : 65536);
         if (dare) {
-            launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s);
+            launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s, max_numel);
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_reduce_kernel<true>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, c.vote_sgn, c.flags);
             MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas, (const int64_t *)nullptr);
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<true>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, c.out, c.flags);
@@ -1906,7 +2019,7 @@ int run_ties(const TiesCall &c) {
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, c.out, c.flags);
         }
     } else if (!bracket) {
-        if (dare) { launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s); launch_merge<true>(p, x, grid, c.out, c.flags, s); }
+        if (dare) { launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s, max_numel); launch_merge<true>(p, x, grid, c.out, c.flags, s); }
         else { launch_radix<false>(p, grid, one_minus_k, c.thresholds_out, s); launch_merge<false>(p, x, grid, c.out, c.flags, s); }
     } else {
         const bool need_count = max_numel > TIES_SAMPLE;
