@@ -313,7 +313,7 @@ def e2e_leg(job: Job, args, rank: int, world: int, dist, device):
             recipe = amd.weighted_sum(models[0], models[1], alpha=0.5)
         from sd_mecha_amd import merging
         out = work / "out.safetensors"
-        times, stats = [], {}
+        times, stats, all_stats = [], {}, []
         for _ in range(args.e2e_reps):
             if rank == 0 and out.exists():
                 out.unlink()
@@ -331,9 +331,13 @@ def e2e_leg(job: Job, args, rank: int, world: int, dist, device):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             times.append(float(t.item()))
             stats = dict(merging.last_stats)
+            all_stats.append(stats)
         link = link_rate(device)
         if rank == 0:
-            best = min(times)
+            # a user calls merge() once per process: the FIRST call is the honest number (it pays the first touch of the pinned
+            # staging buffers and the first read of the input pages); the best later call is reported beside it as "warm"
+            best = times[0]
+            warm = min(times[1:]) if len(times) > 1 else None
             in_bytes = sum(numel(s) * (8 if d.startswith("int") else 2) for _, s, d in job.manifest) * job.n_models
             out_bytes = sum(numel(s) for _, s, _ in job.manifest) * 2
             # every rank has its own link: the slower direction, at the measured pinned rate, over the share of one rank
@@ -343,10 +347,13 @@ def e2e_leg(job: Job, args, rank: int, world: int, dist, device):
                 "seconds": round(best, 4), "all_seconds": [round(x, 4) for x in times], "merged_GBs": round((in_bytes + out_bytes) / best / 1e9, 2),
                 "h2d_GBs": round(in_bytes / best / 1e9, 2), "d2h_GBs": round(out_bytes / best / 1e9, 2),
                 "link_peak_GBs_per_gpu": link, "host_link_frac": round(bound / best, 4), "sink": "file:tmpfs",
+                "seconds_is": "first merge() call of the process (cold)", "warm_seconds": None if warm is None else round(warm, 4),
+                "host_link_frac_warm": None if warm is None else round(bound / warm, 4),
+                "merged_GBs_warm": None if warm is None else round((in_bytes + out_bytes) / warm / 1e9, 2),
                 "scaling": "strong" if world > 1 else "n/a", "n_gpus": world, "keys": len(job.manifest),
                 "fused_keys_rank0": stats.get("fused_keys"), "per_key_path_keys_rank0": stats.get("generic_keys"),
                 "total_buffer_size_gib_per_rank": args.e2e_buffer_gib, "generate_seconds": round(gen_s, 1),
-                "phases_rank0_s": {k: round(v, 3) for k, v in stats.items() if isinstance(v, float)},
+                "phases_rank0_s": [{k: round(v, 3) for k, v in st.items() if isinstance(v, float)} for st in all_stats],
             }
     finally:
         if dist is not None:

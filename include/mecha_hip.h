@@ -410,6 +410,10 @@ int mecha_host_pwrite_many(int fd, const void *const *src, const size_t *nbytes,
 int mecha_host_mmap_write_many(int fd, const void *const *src, const size_t *nbytes,
                                const int64_t *offsets, int64_t n, int threads);
 
+/* n host-to-device copies on one stream, in order: dst_dev[i] <- src_host[i] (nbytes[i] bytes).  For inputs that already sit
+ * in pinned host memory (the reference has no counterpart: its cast node copies from pageable memory, logistics.py:53). */
+int mecha_host_h2d_many(void *const *dst_dev, const void *const *src_host, const size_t *nbytes, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,11 +150,25 @@ int mecha_host_mmap_write_many(int fd, const void *const *src, const size_t *nby
     void *base = mmap(nullptr, (size_t)(hi - map_lo), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)map_lo);
     MECHA_REQUIRE(base != MAP_FAILED, "mmap of the output file failed: %s", strerror(errno));
     const std::vector<Piece> pieces = split(nbytes, n);
-    run_team(pieces, threads, [&](const Piece &p) -> int {
+    const int e = run_team(pieces, threads, [&](const Piece &p) -> int {
         copy_out(static_cast<char *>(base) + (offsets[p.entry] - map_lo) + p.skip, static_cast<const char *>(src[p.entry]) + p.skip, p.len);
         return 0;
     });
     MECHA_REQUIRE(munmap(base, (size_t)(hi - map_lo)) == 0, "munmap failed: %s", strerror(errno));
+    MECHA_REQUIRE(e == 0, "store into the output mapping failed: %s", strerror(e));
+    return MECHA_OK;
+}
+
+// n host-to-device copies enqueued on one stream (the "inputs already in pinned RAM" mode of the scheduler: every (key, model)
+// pair goes from its place in a pinned checkpoint image to its arena offset; a python loop over 10 000 copies costs more than
+// the copies).  `src` must be pinned for the copies to be asynchronous.
+int mecha_host_h2d_many(void *const *dst_dev, const void *const *src_host, const size_t *nbytes, int64_t n, void *stream) {
+    MECHA_REQUIRE(n >= 0 && (n == 0 || (dst_dev != nullptr && src_host != nullptr && nbytes != nullptr)), "NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int64_t i = 0; i < n; i++) {
+        if (nbytes[i] == 0) continue;
+        MECHA_CHECK_HIP(hipMemcpyAsync(dst_dev[i], src_host[i], nbytes[i], hipMemcpyHostToDevice, s));
+    }
     return MECHA_OK;
 }
 

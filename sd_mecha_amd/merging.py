@@ -40,7 +40,7 @@ from . import model_configs
 from .arena import ArenaLayout, plan_arena, shard_keys_lpt
 from .merge_methods import StateDictKeyError
 from .recipe_nodes import LiteralRecipeNode, MergeRecipeNode, ModelRecipeNode, RealizedKeyRelation, RecipeNode, serialize, value_to_node
-from .streaming import DTYPE_REVERSE_MAPPING, InSafetensorsDict, OutSafetensorsDict, TensorMetadata, compact_holes, tensor_bytes
+from .streaming import DTYPE_REVERSE_MAPPING, InSafetensorsDict, OutSafetensorsDict, TensorMetadata, compact_holes, open_reader, tensor_bytes
 
 _DT_CODE = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 log = logging.getLogger("sd_mecha_amd")
@@ -804,7 +804,7 @@ def merge(
     models = collect_models(recipe)
     if not models:
         raise ValueError("the recipe has no model inputs")
-    readers = {id(m): InSafetensorsDict(m.path) for m in models}
+    readers = {id(m): open_reader(m.path) for m in models}
     try:
         plan = fuse(recipe)
         if plan is not None and plan.kind == "rotate" and cache and any(n is plan.node for n in cache):
@@ -975,10 +975,12 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     cap_dev = max((w.layout.total_elems for w in waves), default=128)
     cap = max(cap_dev, piece_elems if split_waves else 0)              # pinned staging: never more than the window
 
+    preloaded = is_cuda and not split_waves and all(hasattr(readers[id(m)], "host_address") for m in plan.models)
+
     def alloc_set():
         pin = dict(pin_memory=True) if is_cuda else {}
         return {
-            "h_in": [torch.empty(cap, dtype=in_dtype, **pin) for _ in range(n_models)],
+            "h_in": [torch.empty(cap if not preloaded else 8, dtype=in_dtype, **pin) for _ in range(n_models)],
             "h_out": None, "out_slot": None,
             "h_flags_pinned": torch.empty(max((len(w.layout.keys) for w in waves), default=1), dtype=torch.int32, **pin),
             "d_in": [torch.empty(cap_dev, dtype=in_dtype, device=dev) for _ in range(n_models)],
@@ -1005,9 +1007,15 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     lora_future = writer.submit(_LoraStore, plan, readers, dev, host_threads) if plan.kind == "lora" else None
     hostlib = _lib.lib()
 
+    # every input already in pinned memory (streaming.preload_pinned): no staging copies, the H2D copies read the images
+    from_pinned = preloaded and plan.kind != "lora"
+    last_stats["source"] = "pinned images" if from_pinned else "files"
+
     def stage(bs, wave: _Wave):
         """files -> pinned staging: one scatter list per wave (every (model, key) pair to its arena offset, and the
         gaps after each key zero-filled so they stay finite), moved by the library's host thread team."""
+        if from_pinned:
+            return
         L = wave.layout
         nk = len(L.keys)
         offs = np.asarray(L.offsets, dtype=np.int64)
@@ -1053,8 +1061,19 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             # the (small, pageable, hence synchronous) segment-table copy goes FIRST: behind the arena copies it would
             # block the host until ~GBs of H2D have drained
             segs_dev = L.device_segments(dev)
-            for mi in range(n_models):
-                bs["d_in"][mi][:L.total_elems].copy_(bs["h_in"][mi][:L.total_elems], non_blocking=True)
+            if from_pinned:
+                import ctypes
+                nk = len(L.keys)
+                offs_b = np.asarray(L.offsets, dtype=np.uint64) * np.uint64(in_esz)
+                sizes = np.ascontiguousarray(np.tile(np.asarray(L.numels, dtype=np.uint64) * np.uint64(in_esz), n_models))
+                dsts = np.ascontiguousarray(np.concatenate([np.uint64(bs["d_in"][mi].data_ptr()) + offs_b for mi in range(n_models)]))
+                srcs = np.ascontiguousarray(np.concatenate([
+                    np.fromiter((readers[id(plan.models[mi])].host_address(k) for k in L.keys), dtype=np.uint64, count=nk) for mi in range(n_models)]))
+                _lib.check(hostlib.mecha_host_h2d_many(dsts.ctypes.data, srcs.ctypes.data, sizes.ctypes.data, len(sizes),
+                                                       ctypes.c_void_p(s_copy_in.cuda_stream)), "mecha_host_h2d_many")
+            else:
+                for mi in range(n_models):
+                    bs["d_in"][mi][:L.total_elems].copy_(bs["h_in"][mi][:L.total_elems], non_blocking=True)
             if is_cuda:
                 bs["ev_h2d"] = torch.cuda.Event()
                 bs["ev_h2d"].record(s_copy_in)
@@ -1224,6 +1243,16 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             sink[key] = t.to(output_device) if output_device not in (None, "cpu") else t
 
     # software pipeline over waves: stage(w+1) on the host overlaps H2D/compute/D2H of w
+    trace = last_stats.setdefault("trace", []) if os.environ.get("MECHA_TRACE") else None
+    if trace is not None:                                     # MECHA_TRACE=1: host seconds of every stage / launch / drain call, in order
+        def timed(name, fn):
+            def run(*a):
+                t0 = time.perf_counter()
+                r = fn(*a)
+                trace.append((name, round(time.perf_counter() - t0, 4)))
+                return r
+            return run
+        stage, launch, drain = timed("stage", stage), timed("launch", launch), timed("drain", drain)
     if waves:
         with _phase("stage"):
             stage(sets[0], waves[0])

@@ -128,3 +128,31 @@ def test_generic_path_threads_match_the_callers_thread(toy_models, tmp_path):   
         raise ValueError("no")
     with pytest.raises(ValueError):
         amd.merge(boom(m[0], m[1]), threads=2, **kw)
+
+
+def test_inputs_preloaded_in_pinned_memory_merge_identically(toy_models):     # noqa: F811
+    """SURVEY.md §8d's "from pinned RAM, no files" mode: with every input preloaded (streaming.preload_pinned) the fused pipeline
+    skips its staging copies and enqueues the H2D copies straight from the pinned images; results are those of the file path."""
+    import sd_mecha_amd as amd
+    from sd_mecha_amd import merging, streaming
+    m = [amd.model(p) for p in toy_models]
+    deltas = [amd.subtract(x, m[0]) for x in m[1:4]]
+    recipe = amd.add_difference(m[0], amd.ties_sum(*deltas, k=0.2), alpha=1.0) | m[0]
+    kw = dict(merge_device="cuda", output_dtype=torch.bfloat16)
+    for buffer in (1 << 31, 1 << 16):
+        want = amd.merge(recipe, total_buffer_size=buffer, **kw)
+        assert merging.last_stats["source"] == "files"
+        try:
+            for p in toy_models:
+                streaming.preload_pinned(p)
+            got = amd.merge(recipe, total_buffer_size=buffer, **kw)
+            # (a job with keys larger than the staging window moves those through the window: it keeps the staging path)
+            want_source = "pinned images" if merging.last_stats["split_keys"] == 0 else "files"
+            assert merging.last_stats["source"] == want_source and (want_source == "files" or merging.last_stats["stage"] < 0.01)
+        finally:
+            streaming.release_pinned()
+        assert sorted(got) == sorted(want)
+        for k in want:
+            if k != "__metadata__":
+                assert torch.equal(got[k], want[k]), k
+    check_against_reference(got, "ties4_fallback", exact=False)

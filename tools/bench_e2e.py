@@ -92,6 +92,12 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/mecha_e2e")
     ap.add_argument("--buffer-gib", type=float, default=16.0, help="total_buffer_size of merge() (pinned staging budget)")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--source", default="files", choices=["files", "pinned"],
+                    help="pinned: the inputs are preloaded into pinned host memory before the timed region (SURVEY.md 8d: isolates the "
+                         "link from the filesystem); the H2D copies read them where they lie")
+    ap.add_argument("--cold", action="store_true",
+                    help="release torch's cached pinned blocks before every repetition: each one then pays the first touch of its staging "
+                         "buffers like the first merge() of a process")
     ap.add_argument("--threads", type=int, default=None, help="merge(threads=...): worker threads of the per-key path (sdxl_rotate)")
     ap.add_argument("--sink", default="file", choices=["file", "none"],
                     help="file: one .safetensors on --dir; none: results come back to pinned host memory and are dropped "
@@ -122,6 +128,10 @@ def main():
                 lora_paths.append(p)
         gen_s = time.perf_counter() - t0
         models = [amd.model(str(p)) for p in paths]
+        if args.source == "pinned":
+            from sd_mecha_amd import streaming
+            for p in paths:
+                streaming.preload_pinned(p)
         if recipe_kind == "lora":
             recipe = models[0]
             for p in lora_paths:
@@ -142,18 +152,20 @@ def main():
             out = work / "out.safetensors"
             if out.exists():
                 out.unlink()
+            if args.cold:
+                torch._C._host_emptyCache()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             from sd_mecha_amd import merging
             amd.merge(recipe, output=str(out) if args.sink == "file" else merging.NullSink(), output_dtype=torch.bfloat16,
                       total_buffer_size=int(args.buffer_gib * 2 ** 30), threads=args.threads)
             times.append(time.perf_counter() - t0)
-            print("phases (host seconds):", {k: round(v, 3) for k, v in merging.last_stats.items()}, file=sys.stderr, flush=True)
+            print("phases (host seconds):", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in merging.last_stats.items()}, file=sys.stderr, flush=True)
         best = min(times)
         line = {
             "metric": "merged state-dict GB/s, end to end (files on tmpfs -> file on tmpfs)" if args.sink == "file" else
                       "merged state-dict GB/s, host-link pipeline (files on tmpfs -> pinned staging -> H2D -> kernels -> D2H -> pinned, no output file)",
-            "workload": args.workload, "sink": args.sink, "threads": args.threads,
+            "workload": args.workload, "sink": args.sink, "source": args.source, "threads": args.threads,
             "value": round(moved / best / 1e9, 2), "unit": "GB/s", "seconds": [round(t, 3) for t in times],
             "bytes_moved": moved, "elements": elems, "keys": len(manifest), "n_models": n_models,
             "total_buffer_size_gib": args.buffer_gib, "host_link_GBs": link_rate(device),
