@@ -84,6 +84,10 @@ def parse_args():
     ap.add_argument("--e2e-dir", default="/dev/shm", help="where the e2e leg keeps its synthetic checkpoints (tmpfs)")
     ap.add_argument("--e2e-buffer-gib", type=float, default=8.0, help="merge(total_buffer_size=...) of the e2e leg, per rank")
     ap.add_argument("--e2e-reps", type=int, default=2)
+    ap.add_argument("--rehearse-staging", action="store_true",
+                    help="CPU only: N gloo ranks each run the real wave plan, staging reads (mecha_host_pread_many) and output writer of the "
+                         "workload's stripe -- no device copies, no kernels -- and rank 0 reports the aggregate host-side GB/s: what the "
+                         "host's DRAM and cores give N ranks before any GPU is involved")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher rehearsal: ranks rendezvous over gloo and report, no GPU work (CPU test of --gpus N)")
     return ap.parse_args()
@@ -388,6 +392,85 @@ def rehearse(args, rank, world):
     dist.destroy_process_group()
 
 
+def rehearse_staging(args, rank, world):
+    """Every rank stages and writes a whole stripe of the workload (weak scaling, like bench.py's GPU run); inputs are ONE set of
+    files on tmpfs shared by the ranks (their pages are read from DRAM by every rank: 24 GB per FLUX stripe do not fit a cache),
+    outputs one file per rank."""
+    import torch.distributed as dist
+    from sd_mecha_amd import merging, numa
+    from sd_mecha_amd.streaming import InSafetensorsDict, OutSafetensorsDict, TensorMetadata
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    manifest_id, comps, n_models, recipe, shards = WORKLOADS[args.workload]
+    manifest = [e for e in load_manifest(manifest_id, comps) if not e[2].startswith("int") and numel(e[1]) > 0]
+    if shards > 1:
+        mine = {k for k, _ in shard_keys_lpt([(k, numel(s)) for k, s, _ in manifest], shards)[0]}
+        manifest = [e for e in manifest if e[0] in mine]
+    work = pathlib.Path(args.e2e_dir) / f"mecha_rehearsal_{os.environ.get('MASTER_PORT', os.getpid())}"
+    header = {k: TensorMetadata(s, torch.bfloat16) for k, s, _ in manifest}
+    items = [(k, numel(s)) for k, s, _ in manifest]
+    in_bytes = sum(n for _, n in items) * 2 * n_models
+    out_bytes = sum(n for _, n in items) * 2
+    bound = numa.bind_rank(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)), None) if world > 1 else None
+    try:
+        if rank == 0:
+            work.mkdir(parents=True, exist_ok=True)
+            block = torch.empty(1 << 26, dtype=torch.bfloat16).normal_(0.0, 0.02)       # 128 MiB of weights, reused for every tensor
+            for m in range(n_models):
+                sink = OutSafetensorsDict(work / f"m{m}.safetensors", header, None)
+                keys = [k for k, _ in items if _ <= block.numel()]
+                sink.put_many(keys, [header[k] for k in keys], [block.data_ptr()] * len(keys), 8)
+                for k, n in items:
+                    if n > block.numel():
+                        sink[k] = block.repeat((n + block.numel() - 1) // block.numel())[:n].reshape(header[k].shape)
+                sink.close()
+        if world > 1:
+            dist.barrier()
+        models = [type("M", (), {"path": work / f"m{m}.safetensors"})() for m in range(n_models)]
+        readers = {id(m): InSafetensorsDict(m.path) for m in models}
+        plan = merging.FusedPlan("navg" if recipe not in ("wsum",) else "wsum", models, {"alpha": 0.5})
+        backend = merging.StagingRehearsalBackend()
+        times, stats = [], {}
+        for rep in range(max(args.e2e_reps, 1)):
+            out = work / f"out{rank}.safetensors"
+            if out.exists():
+                out.unlink()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            merging.last_stats.clear()
+            sink = OutSafetensorsDict(out, header, None)
+            merging._run_fused(plan, backend, readers, items, torch.bfloat16, header, sink, True, "cpu", torch.bfloat16,
+                               int(args.e2e_buffer_gib * 2 ** 30), True, [])
+            sink.close()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            times.append(float(t.item()))
+            stats = dict(merging.last_stats)
+        if rank == 0:
+            best = min(times)
+            print(json.dumps({
+                "rehearsal": "staging", "workload": args.workload, "n_ranks": world, "seconds": [round(x, 3) for x in times],
+                "per_rank_bytes": {"staged_in": in_bytes, "written_out": out_bytes},
+                "aggregate_staging_GBs": round(world * in_bytes / best / 1e9, 2), "aggregate_in_plus_out_GBs": round(world * (in_bytes + out_bytes) / best / 1e9, 2),
+                "per_rank_staging_GBs": round(in_bytes / best / 1e9, 2),
+                "host_threads_per_rank": merging.default_host_threads(), "cpus_visible": os.cpu_count(), "numa_binding_rank0": bound,
+                "pinned_link_rate_needed_per_rank_GBs": 57.6,
+                "phases_rank0_s": {k: round(v, 3) for k, v in stats.items() if isinstance(v, float)},
+                "what": "real wave plan + staging preads (page cache -> staging buffers) + output writer per rank; no device copies, no kernels"}), flush=True)
+        for r in readers.values():
+            r.close()
+    finally:
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(work, ignore_errors=True)
+        if world > 1:
+            dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -395,6 +478,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_staging:
+        return rehearse_staging(args, rank, world)
     if args.rehearse:
         return rehearse(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"

@@ -755,6 +755,23 @@ class _phase:
         last_stats[self.name] = last_stats.get(self.name, 0.0) + time.perf_counter() - self.t0
 
 
+def default_host_threads() -> int:
+    """Threads of this rank's staging / writer team: MECHA_HOST_THREADS, else the cores this process may run on (after the NUMA
+    binding) shared with the other local ranks, at most 16 -- 128 copy threads on a node of 8 ranks helped nobody."""
+    env = os.environ.get("MECHA_HOST_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    _, world, _ = _dist_info()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world)) if world > 1 else 1
+    from . import numa
+    share = cores if numa._bound is not None else cores // max(local_world, 1)      # a bound rank already owns its share
+    return max(2, min(16, share)) if local_world > 1 else max(1, min(16, cores))
+
+
 def _dist_info():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -799,6 +816,15 @@ def merge(
         recipe = recipe | value_to_node(fallback_model)                      # merging.py:154-155
     backend = backend or HipBackend(merge_device)
     rank, world, dist = _dist_info()
+    if world > 1:                                                            # one process per GPU: keep this rank's host side on one NUMA node
+        from . import numa
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        bus = None
+        if backend.device.type == "cuda":
+            pr = torch.cuda.get_device_properties(backend.device)
+            if hasattr(pr, "pci_bus_id") and hasattr(pr, "pci_domain_id"):
+                bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        numa.bind_rank(int(os.environ.get("LOCAL_RANK", rank)) % max(local_world, 1), local_world, bus)
 
     lora_mod.bind_bases(recipe)
     models = collect_models(recipe)
@@ -855,14 +881,13 @@ def merge(
             sizes = [sum(n for _, n in shard) * esz for shard in (shard_keys_lpt(items, world) if world > 1 else [items])]
             region_start = sum(sizes[:rank])
             if world > 1:
-                reserved = [False]
+                # rank 0 creates the file at its full length; then every rank reserves the pages of ITS OWN region in the background
+                # (round 2: rank 0 fallocated the whole file while the others waited on the broadcast)
                 if rank == 0:
-                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=True, region_start=region_start)
-                    reserved[0] = sink.wait_reserved()          # the other ranks store into pages rank 0 allocated
-                dist.broadcast_object_list(reserved, src=0)     # control message; also the "file exists" barrier
+                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=True, region_start=region_start, region_bytes=sizes[0])
+                dist.barrier()                                  # the file exists and has its length
                 if rank != 0:
-                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=False, region_start=region_start,
-                                              pages_reserved=bool(reserved[0]))
+                    sink = OutSafetensorsDict(out_path, header, recipe_text, create=False, region_start=region_start, region_bytes=sizes[rank])
             else:
                 sink = OutSafetensorsDict(out_path, header, recipe_text)
         else:
@@ -947,6 +972,21 @@ def _split_fusable(plan: Optional[FusedPlan], readers, items, header):
     return groups, generic
 
 
+class StagingRehearsalBackend:
+    """``bench.py --rehearse-staging``: the host side of a fused run without a GPU (device copies and kernels left out)."""
+    rehearsal = True
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.methods = mm
+
+    def stream(self):
+        return None
+
+    def workspace_bytes(self, plan, layout, shapes=None):
+        return 0
+
+
 class NullSink(dict):
     """``merge(output=NullSink())``: every key is merged and copied back to pinned host memory, then dropped.  For timing
     the files -> staging -> H2D -> kernels -> D2H pipeline without the cost of an output file (tools/bench_e2e.py --sink none)."""
@@ -976,6 +1016,9 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     cap = max(cap_dev, piece_elems if split_waves else 0)              # pinned staging: never more than the window
 
     preloaded = is_cuda and not split_waves and all(hasattr(readers[id(m)], "host_address") for m in plan.models)
+    # a backend that only rehearses the host side (bench.py --rehearse-staging): real wave plan, real staging reads, real writer;
+    # the device copies and the kernels are left out, the staging buffers stand in for the device arenas
+    rehearsal = bool(getattr(backend, "rehearsal", False))
 
     def alloc_set():
         pin = dict(pin_memory=True) if is_cuda else {}
@@ -983,8 +1026,8 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
             "h_in": [torch.empty(cap if not preloaded else 8, dtype=in_dtype, **pin) for _ in range(n_models)],
             "h_out": None, "out_slot": None,
             "h_flags_pinned": torch.empty(max((len(w.layout.keys) for w in waves), default=1), dtype=torch.int32, **pin),
-            "d_in": [torch.empty(cap_dev, dtype=in_dtype, device=dev) for _ in range(n_models)],
-            "d_out": torch.empty(cap_dev, dtype=output_dtype, device=dev),
+            "d_in": [torch.empty(cap_dev if not rehearsal else 8, dtype=in_dtype, device=dev) for _ in range(n_models)],
+            "d_out": torch.empty(cap_dev if not rehearsal else 8, dtype=output_dtype, device=dev),
             "flags": None, "h_flags": None, "ev_h2d": None, "ev_comp": None, "ev_d2h": None, "wave": None,
         }
     with _phase("alloc"):
@@ -1000,11 +1043,15 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
 
     if hasattr(backend, "prepare"):
         backend.prepare(plan, max(n for _, n in items))
-    host_threads = max(1, min(int(os.environ.get("MECHA_HOST_THREADS", "16")), os.cpu_count() or 1))
+    host_threads = default_host_threads()
     writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     # the LoRA files' factors (pread + H2D + per-file tables) load on a thread of their own beside the staging of the first wave
     lora_store = None
-    lora_future = writer.submit(_LoraStore, plan, readers, dev, host_threads) if plan.kind == "lora" else None
+    def _load_loras():
+        # a new thread's current device is 0, not this rank's: pinned allocations and the host allocator's events would go to GPU 0
+        with (torch.cuda.device(dev) if is_cuda else _null()):
+            return _LoraStore(plan, readers, dev, host_threads)
+    lora_future = writer.submit(_load_loras) if plan.kind == "lora" else None
     hostlib = _lib.lib()
 
     # every input already in pinned memory (streaming.preload_pinned): no staging copies, the H2D copies read the images
@@ -1054,6 +1101,12 @@ def _run_fused(plan, backend, readers, items, in_dtype, header, sink, to_file, o
     def launch(bs, wave: _Wave):
         L = wave.layout
         bs["wave"] = wave
+        if rehearsal:
+            bs["skip"] = ()
+            bs["out_slot"] = next_out()
+            bs["h_out"] = bs["out_slot"]["h_out"]
+            bs["h_flags"] = torch.zeros(len(L.keys), dtype=torch.int32)
+            return
         segs_host = L.host_segments()
         bs["segs_host"] = segs_host
         ctx_in = torch.cuda.stream(s_copy_in) if is_cuda else _null()

@@ -391,3 +391,24 @@ def test_bench_launcher_starts_its_own_ranks():
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["rehearsal"] and line["n_gpus"] == 2
     assert sorted((r["rank"], r["local_rank"]) for r in line["ranks"]) == [(0, 0), (1, 1)]
+
+
+# ------------------------------------------------------------------ multi-rank host placement (round 3)
+def test_numa_plan_and_host_thread_share(monkeypatch):
+    """One process per GPU: a rank's staging team stays on one NUMA node (the GPU's own when sysfs knows it, else an even split)
+    and takes its share of the cores; a single rank or a single node is left alone."""
+    from sd_mecha_amd import merging, numa
+    two = [list(range(0, 64)), list(range(64, 128))]
+    allowed = list(range(128))
+    assert numa.plan(0, 1, two, allowed) is None and numa.plan(0, 8, [allowed], allowed) is None
+    shares = [numa.plan(r, 8, two, allowed) for r in range(8)]
+    assert all(len(s) == 16 for s in shares) and sorted(c for s in shares for c in s) == allowed      # 4 ranks per node, 16 cores each
+    assert all(set(s) <= set(two[r // 4]) for r, s in enumerate(shares))
+    assert numa.plan(5, 8, two, allowed, device_node=0) == two[0]                                    # the GPU's own node wins
+    assert numa.plan(0, 2, two, list(range(60, 70))) == [60, 61, 62, 63]                             # cgroup-restricted mask
+    assert numa.plan(0, 2, two, [64, 65]) is None                                                    # nothing of node 0 is allowed
+    assert numa._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    monkeypatch.delenv("MECHA_HOST_THREADS", raising=False)
+    assert 1 <= merging.default_host_threads() <= 16
+    monkeypatch.setenv("MECHA_HOST_THREADS", "3")
+    assert merging.default_host_threads() == 3
