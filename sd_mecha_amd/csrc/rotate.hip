@@ -127,17 +127,43 @@ struct GemmEpilogue {
     const float *mix;           // if set: v = mix_w0 * mix[idx] + mix_w1 * v, after minus / plus (the alpha interpolation, svd.py:82)
     float mix_w0, mix_w1;
     int64_t out_off;            // element offset of this key inside `out` (set per block from the batch descriptor)
+    // gemm128h_kernel only (its epilogue knows nothing but these and axpy_a / axpy_b; C may be NULL there):
+    _Float16 *sp, *spt;         // if set: the result / its transpose ALSO go out as split-fp16 images (that kernel's operand format)
+    const _Float16 *axpy_img;   // the axpy term, read from its split image (22 of its 24 significand bits)
 };
 // the epilogue of key `key` of a batch: workspace pointers move by the key's workspace stride, `out` by its arena offset
 __device__ __forceinline__ GemmEpilogue epilogue_for_key(GemmEpilogue e, const Batch &bt, int key) {
     e.minus = key_ptr(e.minus, bt, key); e.plus = key_ptr(e.plus, bt, key); e.col_bias = key_ptr(e.col_bias, bt, key);
-    e.axpy = key_ptr(e.axpy, bt, key); e.mix = key_ptr(e.mix, bt, key);
+    e.axpy = key_ptr(e.axpy, bt, key); e.mix = key_ptr(e.mix, bt, key); e.sp = key_ptr(e.sp, bt, key); e.spt = key_ptr(e.spt, bt, key); e.axpy_img = key_ptr(e.axpy_img, bt, key);
     e.out_off = key_off(bt, key);
     if (e.flags != nullptr) e.flags += key;
     return e;
 }
 
-__device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int64_t ldc, int64_t row, int64_t col, float v, bool &bad) {
+// Split-fp16 image of a row-major fp32 matrix with rows of `len` values (len % 8 == 0), the operand format of gemm128h_kernel:
+// every value x is the pair  h = fp16(64 x),  l = fp16(64 x - h)  (22 significand bits; 64: keeps the low parts of entries
+// around 1 / sqrt(r), what a scaled polar iterate holds, out of fp16's subnormal range).  Row m lies at 2 len halves from row
+// m - 1; its k-values go in slots of 8: halves [16 (k >> 3), +8) hold the high parts of k .. k + 7, the next 8 the low parts --
+// a lane's MFMA fragment (8 consecutive k of one row, high and low) is 32 contiguous bytes.
+constexpr float H_SCALE = 64.0f, H_UNSCALE = 1.0f / (64.0f * 64.0f);
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int64_t split_at(int64_t row, int64_t k, int64_t len) { return row * 2 * len + ((k >> 3) << 4) + (k & 7); }
+__device__ __forceinline__ void split_store1(_Float16 *img, int64_t at, float v) {
+    const float sc = v * H_SCALE;
+    const _Float16 h = (_Float16)sc;
+    img[at] = h; img[at + 8] = (_Float16)(sc - (float)h);
+}
+__device__ __forceinline__ float split_load1(const _Float16 *img, int64_t at) { return ((float)img[at] + (float)img[at + 8]) * (1.0f / H_SCALE); }
+// four consecutive k (k % 4 == 0) of one row
+__device__ __forceinline__ void split_store4(_Float16 *img, int64_t at, const f32x4 &v) {
+    const f32x4 sc = v * H_SCALE;
+    const f16x4 h = __builtin_convertvector(sc, f16x4);
+    *reinterpret_cast<f16x4 *>(img + at) = h;
+    *reinterpret_cast<f16x4 *>(img + at + 8) = __builtin_convertvector(sc - __builtin_convertvector(h, f32x4), f16x4);
+}
+
+__device__ __forceinline__ float gemm_store(const GemmEpilogue &e, float *c, int64_t ldc, int64_t row, int64_t col, float v, bool &bad) {
     const int64_t idx = row * ldc + col;
     if (e.axpy != nullptr) v = __builtin_fmaf(e.axpy_a, e.axpy[idx], e.axpy_b * v);
     if (e.minus != nullptr) v = v - e.minus[idx];
@@ -150,6 +176,7 @@ __device__ __forceinline__ void gemm_store(const GemmEpilogue &e, float *c, int6
         else if (e.out_dt == MECHA_F16) store1<MECHA_F16>(e.out, e.out_off + idx, v);
         else store1<MECHA_F32>(e.out, e.out_off + idx, v);
     } else c[idx] = v;
+    return v;
 }
 
 // One operand tile (GK k-values x 64 m-values) of the block: 8 floats per thread, loaded with 16-byte accesses along whichever
@@ -330,6 +357,84 @@ __device__ __forceinline__ void tile_store128(const TileRegs &t, float *lds) {
     }
 }
 
+// The 128 x 128 block's epilogue: accumulator register r of lane (i, kk) is C[32 tm + (r & 3) + 8 (r >> 2) + 4 kk][32 tn + i] of the wave's
+// 64 x 64 tile, so a lane holds 4 consecutive rows of one column per register group: whatever is stored transposed (the mirror
+// tile of a symmetric product, an image of the transpose) goes out as 16 (fp32) or 2 x 8 (split image) contiguous bytes per lane.
+// symmetric: the epilogue is at most the axpy of a symmetric matrix; mirror: the tile lies above the diagonal.
+__device__ __forceinline__ void gemm128_finish(f32x16 (&acc)[2][2], float *c, const GemmEpilogue &ee, int64_t M, int64_t N, int64_t bm0, int64_t bn0,
+                                               int wm, int wn, int i, int kk, bool symmetric, bool mirror) {
+    bool bad = false;
+    if (symmetric) {
+        const bool vec = (N & 3) == 0;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int64_t row0 = bm0 + wm + 32 * tm + 8 * g4 + 4 * kk, col = bn0 + wn + 32 * tn + i;
+                    f32x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float v = acc[tm][tn][4 * g4 + j];
+                        const int64_t row = row0 + j;
+                        if (row < M && col < N) {
+                            if (ee.axpy != nullptr) v = __builtin_fmaf(ee.axpy_a, ee.axpy[row * N + col], ee.axpy_b * v);
+                            c[row * N + col] = v;
+                        }
+                        v4[j] = v;
+                    }
+                    if (mirror && col < N) {
+                        if (vec && row0 + 4 <= M) *reinterpret_cast<f32x4 *>(c + col * N + row0) = v4;
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (row0 + j < M) c[col * N + row0 + j] = v4[j];
+                        }
+                    }
+                }
+        return;
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t row = bm0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * kk, col = bn0 + wn + 32 * tn + i;
+                if (row < M && col < N) gemm_store(ee, c, N, row, col, acc[tm][tn][r], bad);
+            }
+    if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
+}
+// gemm128h_kernel's: v = axpy_a * axpy_img + axpy_b * acc; fp32 C if given; the image `sp` (with the mirror tile of a symmetric
+// product) and the transpose's image `spt`.  M % 4 == 0 (images have rows of whole slots).
+__device__ __forceinline__ void gemm128h_finish(f32x16 (&acc)[2][2], float *c, const GemmEpilogue &ee, int64_t M, int64_t N, int64_t bm0, int64_t bn0,
+                                                int wm, int wn, int i, int kk, bool symmetric, bool mirror) {
+    _Float16 *tsp = symmetric ? (mirror ? ee.sp : nullptr) : ee.spt;
+    float *tc = (symmetric && mirror) ? c : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int64_t row0 = bm0 + wm + 32 * tm + 8 * g4 + 4 * kk, col = bn0 + wn + 32 * tn + i;
+                if (row0 >= M || col >= N) continue;            // (whole groups: M % 4 == 0)
+                f32x4 v4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float v = acc[tm][tn][4 * g4 + j];
+                    const int64_t at = split_at(row0 + j, col, N);
+                    if (ee.axpy_img != nullptr) v = __builtin_fmaf(ee.axpy_a, split_load1(ee.axpy_img, at), ee.axpy_b * v);
+                    if (c != nullptr) c[(row0 + j) * N + col] = v;
+                    if (ee.sp != nullptr) split_store1(ee.sp, at, v);
+                    v4[j] = v;
+                }
+                if (tsp != nullptr) split_store4(tsp, split_at(col, row0, M), v4);
+                if (tc != nullptr) *reinterpret_cast<f32x4 *>(tc + col * M + row0) = v4;
+            }
+}
+
 // symmetric: A and B are the same operand (C = X X^T, or G G of a symmetric G) and the epilogue is at most the axpy of a
 // symmetric matrix.  Only the tiles on and above the diagonal are computed; a tile above it is also stored transposed
 // (every lane holds 4 consecutive rows of one column = 16 contiguous bytes of the transposed tile).  The result is symmetric
@@ -393,49 +498,188 @@ __global__ __launch_bounds__(256, 3) void gemm128_kernel(Operand A, Operand B, f
     float *c = C + (int64_t)slab * M * N;
     GemmEpilogue ee = epilogue_for_key(e, bt, key);
     if (n_slabs > 1) ee = GemmEpilogue{};                       // the epilogue then runs in gemm_reduce
-    bool bad = false;
-    if (symmetric) {
-        const bool mirror = bx > by;
-        const bool vec = (N & 3) == 0;
+    gemm128_finish(acc, c, ee, M, N, bm0, bn0, wm, wn, i, kk, symmetric != 0, bx > by);
+}
+
+// ------------------------------------------------------------------------------------------------ split-fp16 GEMM
+// The same 128 x 128 product on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA's rate) from operands kept as split-fp16 images
+// (split_at above): the product is the three MFMAs  h_a h_b + h_a l_b + l_a h_b  accumulated in fp32 (the dropped l_a l_b term
+// is 2^-22 of the product), scaled back by 2^-12 at the end, exactly.  So a result carries ~5e-7 relative error per product term
+// against 6e-8 for the fp32 instruction: used for the polar steps that later fp32 steps correct (polar_newton_schulz), never for a
+// step whose output is final.  Operands are bounded there (|x| <= ~6 for every matrix of a scaled iteration), far from fp16's
+// 65504 / 64.  The images are made once, by the epilogue of the product that made the matrix (GemmEpilogue::sp / spt) or by
+// rot_split_kernel -- converting in this kernel's loop, the first version, cost as many VALU cycles as the MFMAs took
+// (profiles/r03_rotate_notes.md), once per consuming block instead of once per value.
+// Both operands are k-contiguous by construction (rows of an image).  LDS holds a chunk as two planes [row][k] (high parts, low
+// parts): a lane's fragment is one ds_read_b128 from each.  The 16-byte slots of a row are XOR-swizzled with row bits so that
+// the 16 lanes ds_read_b128 serves per LDS cycle (MI355X_MICROARCH.md, LDS: lanes {0-3, 12-15, 20-27}, ...) touch 16 different slots.
+// HK: k-chunk per LDS buffer, 16 or 32 (a plane row is then 32 or 64 bytes; 32 or 64 KiB of LDS per block).
+struct HOperand { const _Float16 *p; int64_t ms; };            // image base, halves between rows (2 x row length)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// offset (in halves) of 16-byte slot `slot` (8 k-values) of row `row` in a plane (128 x HK halves)
+template <int HK> __device__ __forceinline__ int h_slot(int row, int slot) {
+    const int sw = HK == 16 ? ((row >> 3) & 1) : ((row >> 2) & 3);
+    return row * HK + ((slot ^ sw) << 3);
+}
+// One operand chunk (128 rows x HK k-values, high and low parts: 128 x 4 HK bytes) is 512 HK / 16 pieces of 16 bytes; thread tid
+// takes pieces tid, tid + 256, ...: piece e = (row e / LPR, 16-byte unit e % LPR of the row's 4 HK contiguous bytes), unit u =
+// (slot u >> 1, high | low part u & 1).  A wave instruction so reads whole rows' contiguous bytes (HK = 32: 8 full 128-byte lines).
+template <int HK> struct HTileRegs { u32x4_t v[HK / 8]; };
+template <int HK> __device__ __forceinline__ HTileRegs<HK> h_tile_load(const HOperand &op, int64_t m0, int64_t M, int64_t k0, int64_t k_end) {
+    constexpr int LPR = HK / 4, RPP = 256 / LPR;
+    HTileRegs<HK> t;
+    const int tid = threadIdx.x, u = tid % LPR;
+    const int64_t k = k0 + 8 * (u >> 1);
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const int64_t row0 = bm0 + wm + 32 * tm + 8 * g4 + 4 * kk, col = bn0 + wn + 32 * tn + i;
-                    f32x4 v4;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        float v = acc[tm][tn][4 * g4 + j];
-                        const int64_t row = row0 + j;
-                        if (row < M && col < N) {
-                            if (ee.axpy != nullptr) v = __builtin_fmaf(ee.axpy_a, ee.axpy[row * N + col], ee.axpy_b * v);
-                            c[row * N + col] = v;
-                        }
-                        v4[j] = v;
-                    }
-                    if (mirror && col < N) {
-                        if (vec && row0 + 4 <= M) *reinterpret_cast<f32x4 *>(c + col * N + row0) = v4;
-                        else {
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if (row0 + j < M) c[col * N + row0 + j] = v4[j];
-                        }
-                    }
-                }
-        return;
+    for (int h = 0; h < HK / 8; h++) {
+        const int64_t m = m0 + tid / LPR + RPP * h;
+        if (m < M && k < k_end) t.v[h] = *reinterpret_cast<const u32x4_t *>(op.p + m * op.ms + 2 * k + 8 * (u & 1));   // (k_end % 8 == 0: whole slots)
+        else t.v[h] = u32x4_t{0u, 0u, 0u, 0u};
     }
+    return t;
+}
+template <int HK> __device__ __forceinline__ void h_tile_store(const HTileRegs<HK> &t, _Float16 *lds) {
+    constexpr int LPR = HK / 4, RPP = 256 / LPR, H_PLANE = 128 * HK;
+    const int tid = threadIdx.x, u = tid % LPR;
+#pragma unroll
+    for (int h = 0; h < HK / 8; h++)
+        *reinterpret_cast<u32x4_t *>(lds + (u & 1) * H_PLANE + h_slot<HK>(tid / LPR + RPP * h, u >> 1)) = t.v[h];
+}
+
+// D: chunks of register prefetch.  The operand loads come from L2 or beyond at ~2 us under this kernel's own load (measured:
+// throughput followed the bytes in flight per CU, whatever the chunk size, load shape or blocks per CU), so a block keeps D chunks
+// in flight: at the top of chunk c's iteration ring slot c % D holds chunk c + 1 and the others chunks c + 2 .. c + D; after
+// the MFMAs of chunk c, slot c % D goes to the other LDS buffer and is reloaded with chunk c + D + 1.
+template <int HK, int D>
+__global__ __launch_bounds__(256, (HK == 16 && D == 1) ? 3 : 2) void gemm128h_kernel(HOperand A, HOperand B, float *C, int64_t M, int64_t N, int64_t K, int64_t k_per_slab,
+                                                                                   int n_slabs, Batch bt, GemmEpilogue e, int symmetric) {
+    constexpr int H_PLANE = 128 * HK;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2][2][2 * H_PLANE];   // [buffer][A | B][high plane, low plane]
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (MECHA_ROT_XCD_MAP) {                                    // as gemm128_kernel: an XCD takes a contiguous range of the tiles
+        const uint64_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint64_t id = bx + gx * (by + gy * (uint64_t)bz), xcd = id & 7u;
+        const uint64_t logical = xcd * (total >> 3) + (xcd < (total & 7u) ? xcd : (total & 7u)) + (id >> 3);
+        bx = (unsigned)(logical % gx); by = (unsigned)((logical / gx) % gy); bz = (unsigned)(logical / (gx * gy));
+    }
+    const int key = bz / n_slabs, slab = bz - key * n_slabs;
+    if (symmetric && bx < by) return;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    A.p = key_ptr(A.p, bt, key); B.p = key_ptr(B.p, bt, key); C = key_ptr(C, bt, key);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int64_t bm0 = (int64_t)by * 128, bn0 = (int64_t)bx * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int64_t k_begin = (int64_t)slab * k_per_slab;
+    const int64_t k_end = (k_begin + k_per_slab < K) ? k_begin + k_per_slab : K;
+    const int64_t n_chunks = (k_end - k_begin + HK - 1) / HK;
+    f32x16 acc[2][2];
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
         for (int tn = 0; tn < 2; tn++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int64_t row = bm0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * kk, col = bn0 + wn + 32 * tn + i;
-                if (row < M && col < N) gemm_store(ee, c, N, row, col, acc[tm][tn][r], bad);
+            for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
+    HTileRegs<HK> ra[D], rb[D];
+    {
+        const HTileRegs<HK> a0 = h_tile_load<HK>(A, bm0, M, k_begin, k_end), b0 = h_tile_load<HK>(B, bn0, N, k_begin, k_end);
+#pragma unroll
+        for (int j = 0; j < D; j++) {                           // (chunks past the end load nothing: zeros)
+            ra[j] = h_tile_load<HK>(A, bm0, M, k_begin + (j + 1) * HK, k_end);
+            rb[j] = h_tile_load<HK>(B, bn0, N, k_begin + (j + 1) * HK, k_end);
+        }
+        h_tile_store<HK>(a0, lds[0][0]);
+        h_tile_store<HK>(b0, lds[0][1]);
+    }
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const int64_t c = c0 + j;
+            if (c >= n_chunks) break;
+            const int buf = (int)(c & 1);
+            const _Float16 *pa = lds[buf][0], *pb = lds[buf][1];
+#pragma unroll
+            for (int s = 0; s < HK / 16; s++) {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int oa = h_slot<HK>(wm + 32 * t + i, 2 * s + kk), ob = h_slot<HK>(wn + 32 * t + i, 2 * s + kk);
+                    ah[t] = *reinterpret_cast<const f16x8 *>(pa + oa); al[t] = *reinterpret_cast<const f16x8 *>(pa + H_PLANE + oa);
+                    bh[t] = *reinterpret_cast<const f16x8 *>(pb + ob); bl[t] = *reinterpret_cast<const f16x8 *>(pb + H_PLANE + ob);
+                }
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
             }
-    if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
+            if (c + 1 < n_chunks) { h_tile_store<HK>(ra[j], lds[buf ^ 1][0]); h_tile_store<HK>(rb[j], lds[buf ^ 1][1]); }
+            ra[j] = h_tile_load<HK>(A, bm0, M, k_begin + (c + 1 + D) * HK, k_end);
+            rb[j] = h_tile_load<HK>(B, bn0, N, k_begin + (c + 1 + D) * HK, k_end);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) acc[tm][tn] *= H_UNSCALE;
+    float *c = (C == nullptr) ? nullptr : C + (int64_t)slab * M * N;
+    GemmEpilogue ee = epilogue_for_key(e, bt, key);
+    if (n_slabs > 1) ee = GemmEpilogue{};
+    gemm128h_finish(acc, c, ee, M, N, bm0, bn0, wm, wn, i, kk, symmetric != 0, bx > by);
+}
+
+// The factor a key's matrix is multiplied by on its way into an image (rot_split_kernel), from the key's scalars:
+//   scal[2] = |X|_F^2 of the unscaled matrix  ->  t = 2^-ceil(log2 |X|_F): t X has every entry and singular value <= 1, exactly;
+//   scal[0] = |G|_F^2 of G = (t X)(t X)^T      ->  s = |G|_F^(-1/2) <= 1 / sigma_max(t X), the polar iteration's scaling.
+enum : int { SPLIT_PLAIN = 0, SPLIT_T = 1, SPLIT_TS = 2, SPLIT_SS = 3 };      // x,  t x,  t s x,  s^2 x
+__device__ __forceinline__ float split_factor(int mode, const double *scal) {
+    if (mode == SPLIT_PLAIN) return 1.0f;
+    const double ss = scal[2], h = scal[0];
+    const double t = (ss > 1e-150 && ss < 1e150) ? exp2(-ceil(0.5 * log2(ss))) : (ss == ss ? 0.0 : ss);
+    if (mode == SPLIT_T) return (float)t;
+    const double s = (h > 0.0 && h < 1e300) ? 1.0 / sqrt(sqrt(h)) : (h == h ? 0.0 : h);
+    return mode == SPLIT_TS ? (float)(t * s) : (float)(s * s);
+}
+// sp = the split image of f x (x: r x c row-major fp32, f: split_factor), spt (nullable) = the image of its transpose; every key of
+// the batch that `skip` does not excuse.  64 x 64 tiles through LDS.  r % 8 == 0 and c % 8 == 0.
+__global__ __launch_bounds__(256) void rot_split_kernel(const float *x, _Float16 *sp, _Float16 *spt, int64_t r, int64_t c, int mode, const double *scal, Batch bt) {
+    __shared__ float tile[64][65];
+    const int key = blockIdx.z;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    x = key_ptr(x, bt, key); sp = key_ptr(sp, bt, key); spt = key_ptr(spt, bt, key);
+    const float f = split_factor(mode, key_ptr(scal, bt, key));
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4)
+        if (r0 + j < r && c0 + tx < c) {
+            const float v = x[(r0 + j) * c + c0 + tx] * f;
+            tile[j][tx] = v;
+            split_store1(sp, split_at(r0 + j, c0 + tx, c), v);
+        }
+    if (spt == nullptr) return;
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4)
+        if (c0 + j < c && r0 + tx < r) split_store1(spt, split_at(c0 + j, r0 + tx, r), tile[tx][j]);
+}
+// scal[2] += sum x^2 (fp64; zeroed by the host)
+__global__ __launch_bounds__(256) void rot_sumsq_kernel(const float *x, int64_t n, double *scal, Batch bt) {
+    __shared__ double sh[4];
+    const int key = blockIdx.y;
+    if (bt.skip != nullptr && bt.skip[key] != 0u) return;
+    x = key_ptr(x, bt, key); scal = key_ptr(scal, bt, key);
+    double s0 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = (double)x[i]; s0 += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s0 += __shfl_down(s0, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s0;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&scal[2], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, int n_slabs, float *C, int64_t M, int64_t N, GemmEpilogue e, Batch bt) {
@@ -449,7 +693,12 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
         const int64_t row = t / N, col = t - row * N;
         float s = 0.0f;
         for (int z = 0; z < n_slabs; z++) s += slabs[(int64_t)z * total + t];
-        gemm_store(e, C, N, row, col, s, bad);
+        if (e.sp != nullptr || e.spt != nullptr || e.axpy_img != nullptr) {          // a product of gemm128h_kernel
+            if (e.axpy_img != nullptr) s = __builtin_fmaf(e.axpy_a, split_load1(e.axpy_img, split_at(row, col, N)), e.axpy_b * s);
+            if (C != nullptr) C[t] = s;
+            if (e.sp != nullptr) split_store1(e.sp, split_at(row, col, N), s);
+            if (e.spt != nullptr) split_store1(e.spt, split_at(col, row, M), s);
+        } else gemm_store(e, C, N, row, col, s, bad);
     }
     if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
@@ -543,6 +792,38 @@ void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, const
 #undef MECHA_GEMM128
     }
     else MECHA_LAUNCH(MK_ROT_GEMM, gemm_kernel, grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none);
+    if (z > 1) {
+        const int64_t total = M * N;
+        const int64_t want = (total + 255) / 256, cap = count >= 64 ? 16 : 1024 / count;
+        MECHA_LAUNCH(MK_ROT_GEMM, gemm_reduce_kernel, dim3((unsigned)(want < cap ? want : cap), (unsigned)count), dim3(256), 0, g.s, g.slabs, (int)z, C, M, N, e, g.bt);
+    }
+}
+
+// C[m][n] = sum_k a[m][k] b[n][k] from the split-fp16 images of a (M x K) and b (N x K); M, N >= 256, K % 8 == 0.  Same slab
+// logic as gemm().  32-deep k-chunks, two in flight (measured best: 1.123 s against 1.149 s for MECHA_ROT_HK=16, one in flight,
+// on the 1071 SDXL keys).
+void gemm_h(const _Float16 *a, const _Float16 *b, float *C, int64_t M, int64_t N, int64_t K, const GemmEpilogue &e, const GemmCtx &g, bool symmetric = false) {
+    static const int hk = [] { const char *v = getenv("MECHA_ROT_HK"); return v != nullptr && atoi(v) == 16 ? 16 : 32; }();
+    const int count = g.bt.count;
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128) * count;
+    int64_t z = 512 / tiles;
+    const int64_t zmax = (K + 127) / 128;
+    if (z > zmax) z = zmax;
+    if (z > GRID_Z_MAX / count) z = GRID_Z_MAX / count;
+    while (z > 1 && (size_t)z * (size_t)M * (size_t)N > g.slab_floats) z--;
+    if (z < 1) z = 1;
+    int64_t k_per = (K + z - 1) / z;
+    k_per = (k_per + hk - 1) / hk * hk;
+    z = (K + k_per - 1) / k_per;
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)(z * count)), block(256);
+    float *dst = z == 1 ? C : g.slabs;
+    const GemmEpilogue none{};
+    const int sym = (symmetric && z == 1 && M == N && e.spt == nullptr) ? 1 : 0;
+    const HOperand A{a, 2 * K}, B{b, 2 * K};
+#define MECHA_GEMMH(HK_, D_) MECHA_LAUNCH(MK_ROT_GEMM, (gemm128h_kernel<HK_, D_>), grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none, sym)
+    if (hk == 32) MECHA_GEMMH(32, 2);
+    else MECHA_GEMMH(16, 1);
+#undef MECHA_GEMMH
     if (z > 1) {
         const int64_t total = M * N;
         const int64_t want = (total + 255) / 256, cap = count >= 64 ? 16 : 1024 / count;
@@ -681,14 +962,14 @@ __global__ __launch_bounds__(64) void rot_converged_kernel(const double *scal, d
     done[key] = (err2 == err2 && err2 <= null_dirs + tol) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(64) void rot_zero_scal_kernel(double *scal, Batch bt) {
+__global__ __launch_bounds__(64) void rot_zero_scal_kernel(double *scal, int slot, Batch bt) {
     const int key = blockIdx.x * 64 + threadIdx.x;
-    if (key < bt.count) { double *s = key_ptr(scal, bt, key); s[0] = 0.0; s[1] = 0.0; }
+    if (key < bt.count) { double *s = key_ptr(scal, bt, key); s[slot] = 0.0; s[slot + 1] = 0.0; }
 }
 // scal[0] = |G|_F^2, scal[1] = |G - I|_F^2 of every key's r x r Gram matrix
 void gram_norms(const float *G, int64_t r, double *scal, const GemmCtx &g) {
     const int count = g.bt.count;
-    MECHA_LAUNCH(MK_ROT_NORMS, rot_zero_scal_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, g.s, scal, g.bt);
+    MECHA_LAUNCH(MK_ROT_NORMS, rot_zero_scal_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, g.s, scal, 0, g.bt);
     const int64_t nbw = (r * r + 255) / 256, nb_cap = count >= 64 ? 16 : 1024 / count;
     MECHA_LAUNCH(MK_ROT_NORMS, rot_gram_norms_kernel, dim3((unsigned)(nbw < nb_cap ? nbw : nb_cap), (unsigned)count), dim3(256), 0, g.s, G, r, scal, g.bt);
 }
@@ -721,6 +1002,30 @@ float *polar_step(float *cur, float *nxt, float *G, float *G2, int64_t r, int64_
     return nxt;
 }
 
+// The split-fp16 images a run of steps on gemm128h_kernel keeps beside the fp32 iterate: of the iterate and its transpose
+// (two of each: current and next), of G and of b G + c G^2.
+struct PolarImages { _Float16 *x[2], *xt[2], *g, *g2; };
+// The same step on the split-fp16 kernel.  x_img / xt_img: images of cur and cur^T; all three products read rows of images:
+// X X^T along the rows of X, G G along the rows of the symmetric G, G2 X as (rows of G2) x (rows of X^T).  G and b G + c G^2
+// exist only as images, the axpy terms are read back from images (a batch streams every matrix from HBM -- ~100 flop per byte --
+// so the bytes count: fp32 copies beside the images made such a step 1.6x the traffic).  The new iterate goes out as fp32 when
+// an fp32 step follows (nxt != NULL) and as its two images when another step of this kind does.
+// have_gram: g_img already holds the image of X X^T (the first step of a run makes it while it scales the iterate).
+void polar_step_h(float *nxt, int64_t r, int64_t c, const PolarStep &st, const GemmCtx &g, const _Float16 *x_img, const _Float16 *xt_img,
+                  _Float16 *g_img, _Float16 *g2_img, _Float16 *nx_img, _Float16 *nxt_img, bool have_gram = false) {
+    if (!have_gram) {
+        GemmEpilogue gram{};
+        gram.sp = g_img;
+        gemm_h(x_img, x_img, nullptr, r, r, c, gram, g, true);
+    }
+    GemmEpilogue mix{};
+    mix.axpy_img = g_img; mix.axpy_a = st.b; mix.axpy_b = st.c; mix.sp = g2_img;
+    gemm_h(g_img, g_img, nullptr, r, r, r, mix, g, true);
+    GemmEpilogue upd{};
+    upd.axpy_img = x_img; upd.axpy_a = st.a; upd.axpy_b = 1.0f; upd.sp = nx_img; upd.spt = nxt_img;
+    gemm_h(g2_img, xt_img, nxt, r, c, r, upd, g);
+}
+
 // Polar factor of every key's X (r x c, r <= c), in place.
 //   optimistic == false: the 14-step schedule made for singular values down to 1e-7 of the largest.
 //   optimistic == true (wide keys: well conditioned as a rule -- a Gaussian n x p matrix has all its singular values
@@ -730,28 +1035,77 @@ float *polar_step(float *cur, float *nxt, float *G, float *G2, int64_t r, int64_
 //       it on a matrix that is already partly converged is safe).  The host never learns which keys left: the later
 //       launches are enqueued for the whole batch and their blocks exit on the key's done word.
 // done: per-key device words (used only when optimistic).
+// img (nullable): buffers for split-fp16 images; with them, and r >= 256, r and c multiples of 8, every step but the first of a run
+//       (whose Gram matrix scales X) and the last POLAR_F32_TAIL of a schedule runs on the split-fp16 kernel (polar_step_h): each step's rounding
+//       is a perturbation of the iterate that the following steps pull back to the same polar factor to first order (the
+//       factor of X + D differs from that of X by ~|D| / (s_i + s_j) between singular directions i, j, the same sensitivity
+//       the fp32 products have at a 10x smaller |D|), and the closing fp32 steps set the final orthogonality.
+//       MECHA_ROT_PREC=f32 keeps every step on the fp32 kernel; MECHA_ROT_F32_TAIL=<n> overrides the tail length (tests).
+constexpr int POLAR_F32_TAIL = 0;
 int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, int64_t c, double *scal, uint32_t *done, int *iters_out,
-                        const GemmCtx &g_in, bool deflate_ones, bool optimistic) {
+                        const GemmCtx &g_in, bool deflate_ones, bool optimistic, const PolarImages *img = nullptr) {
     GemmCtx g = g_in;
     // MECHA_ROT_POLAR=long: no optimistic phase; =both: every key goes through both schedules (tests of the fall-through)
     const char *mode = getenv("MECHA_ROT_POLAR");
     if (mode != nullptr && strcmp(mode, "long") == 0) optimistic = false;
     const bool force_both = mode != nullptr && strcmp(mode, "both") == 0;
+    const char *prec = getenv("MECHA_ROT_PREC"), *tail_env = getenv("MECHA_ROT_F32_TAIL");
+    const bool split_ok = img != nullptr && r >= 256 && (r & 7) == 0 && (c & 7) == 0 && !(prec != nullptr && strcmp(prec, "f32") == 0);
+    const int f32_tail = tail_env != nullptr ? atoi(tail_env) : POLAR_F32_TAIL;
     float *cur = X, *nxt = tmp;
+    int ib = 0;                                                 // img->x[ib], img->xt[ib]: the images of cur and cur^T ...
+    bool t_valid = false;                                       // ... when this says so
     const int count = g.bt.count;
     auto deflate = [&](int it, int n_steps) {
-        if (deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == n_steps))
+        if (deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == n_steps)) {
             MECHA_LAUNCH(MK_ROT_NORMS, rot_deflate_ones_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)count), dim3(256), 0, g.s, cur, r, c, g.bt);
+            t_valid = false;
+        }
+    };
+    bool first = true;
+    // step `it` of an n-step schedule
+    auto step = [&](const PolarStep &st, int it, int n_steps) {
+        const bool split = split_ok && it < n_steps - f32_tail;
+        float *out;
+        if (split) {
+            const dim3 sgrid((unsigned)((c + 63) / 64), (unsigned)((r + 63) / 64), (unsigned)count);
+            if (first) {
+                // The scaling of the first step, without an fp32 product: images of t X (t: a power of two that brings |X|_F to
+                // <= 1), G = (t X)(t X)^T from them in fp32, its norm -> s; then the images of t s X and of s^2 G.  The fp32 X
+                // itself stays unscaled: nothing reads it again (the axpy terms come from images, the last step of the run
+                // writes the fp32 iterate).
+                MECHA_LAUNCH(MK_ROT_NORMS, rot_zero_scal_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, g.s, scal, 2, g.bt);
+                const int64_t nbw = (r * c + 255) / 256, nb_cap = count >= 64 ? 16 : 1024 / count;
+                MECHA_LAUNCH(MK_ROT_NORMS, rot_sumsq_kernel, dim3((unsigned)(nbw < nb_cap ? nbw : nb_cap), (unsigned)count), dim3(256), 0, g.s, cur, r * c, scal, g.bt);
+                MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, sgrid, dim3(256), 0, g.s, cur, img->x[ib], (_Float16 *)nullptr, r, c, (int)SPLIT_T, scal, g.bt);
+                const GemmEpilogue none{};
+                gemm_h(img->x[ib], img->x[ib], G, r, r, c, none, g, true);
+                gram_norms(G, r, scal, g);
+                MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, sgrid, dim3(256), 0, g.s, cur, img->x[ib], img->xt[ib], r, c, (int)SPLIT_TS, scal, g.bt);
+                MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, dim3((unsigned)((r + 63) / 64), (unsigned)((r + 63) / 64), (unsigned)count), dim3(256), 0, g.s,
+                             G, img->g, (_Float16 *)nullptr, r, r, (int)SPLIT_SS, scal, g.bt);
+            } else if (!t_valid)
+                MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, sgrid, dim3(256), 0, g.s, cur, img->x[ib], img->xt[ib], r, c, (int)SPLIT_PLAIN, scal, g.bt);
+            // images for the next step unless it is an fp32 step or the deflation (which works on the fp32 iterate) comes first
+            const bool deflates = deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == n_steps);
+            const bool next_split = it + 1 < n_steps - f32_tail && !deflates;
+            // (the fp32 iterate is written by the last step of such a run only; in between, `nxt` is a stale buffer)
+            polar_step_h(next_split ? nullptr : nxt, r, c, st, g, img->x[ib], img->xt[ib], img->g, img->g2, next_split ? img->x[ib ^ 1] : nullptr,
+                         next_split ? img->xt[ib ^ 1] : nullptr, first);
+            out = nxt;
+            ib ^= 1;
+            t_valid = next_split;
+        } else {
+            out = polar_step(cur, nxt, G, G2, r, c, scal, st, first, g);
+            t_valid = false;
+        }
+        nxt = cur; cur = out; first = false;
+        deflate(it, n_steps);
     };
     int steps = 0;
-    bool first = true;
     if (optimistic) {
         const PolarSchedule &easy = polar_schedule_easy();
-        for (int it = 0; it < easy.n; it++) {
-            float *out = polar_step(cur, nxt, G, G2, r, c, scal, easy.step[it], first, g);
-            nxt = cur; cur = out; first = false;
-            deflate(it, easy.n);
-        }
+        for (int it = 0; it < easy.n; it++) step(easy.step[it], it, easy.n);
         steps += easy.n;
         // has every singular value arrived?  G of the current X, its distance from the identity, one word per key
         const GemmEpilogue none{};
@@ -769,6 +1123,7 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
                                              hipMemcpyDeviceToDevice, g.s));
             cur = X; nxt = tmp;
         }
+        t_valid = false;
         g.bt.skip = done;
     }
     const PolarSchedule &ps = polar_schedule();
@@ -783,9 +1138,7 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
             const float h = 0.97f, h3 = h * h * h;
             st = PolarStep{st.a * h, st.b * h3, st.c * h3 * h * h};
         }
-        float *out = polar_step(cur, nxt, G, G2, r, c, scal, st, first, g);
-        nxt = cur; cur = out; first = false;
-        deflate(it, ps.n);
+        step(st, it, ps.n);
     }
     steps += ps.n;
     if (iters_out) *iters_out += steps;
@@ -800,7 +1153,7 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
 
 // Private workspace of one key, as offsets from its start; the same for every key of a shape.
 struct RotLayout {
-    size_t scal, part, a_mean, b_mean, t_mean, ac, bc, y, slabs, m0, m1, m2, m3, m4, m5, m6, m7, total;
+    size_t scal, part, a_mean, b_mean, t_mean, ac, bc, y, slabs, m0, m1, m2, m3, m4, m5, m6, m7, img_x0, img_x1, img_xt0, img_xt1, img_g, img_g2, total;
     size_t slab_floats;
 };
 RotLayout rot_layout(int64_t n, int64_t p, int count) {
@@ -823,9 +1176,12 @@ RotLayout rot_layout(int64_t n, int64_t p, int count) {
     L.slabs = fl(slab);
     if (n >= p) {                                               // M -> R, its Newton-Schulz twin, G, b G + c G^2
         L.m0 = fl(p * p); L.m1 = fl(p * p); L.m2 = fl(p * p); L.m3 = fl(p * p);
+        // split-fp16 images (4 bytes a value, as fp32): the iterate, its transpose (current and next), G, b G + c G^2
+        L.img_x0 = fl(p * p); L.img_x1 = fl(p * p); L.img_xt0 = fl(p * p); L.img_xt1 = fl(p * p); L.img_g = fl(p * p); L.img_g2 = fl(p * p);
     } else {                                                    // Qb^T, Z, twin; G, b G + c G^2, P, x P2^T, D
         L.m0 = fl(n * p); L.m1 = fl(n * p); L.m2 = fl(n * p);
         L.m3 = fl(n * n); L.m4 = fl(n * n); L.m5 = fl(n * n); L.m6 = fl(n * n); L.m7 = fl(n * n);
+        L.img_x0 = fl(n * p); L.img_x1 = fl(n * p); L.img_xt0 = fl(n * p); L.img_xt1 = fl(n * p); L.img_g = fl(n * n); L.img_g2 = fl(n * n);
     }
     L.total = up256(cursor);
     return L;
@@ -913,6 +1269,8 @@ int rotate_run(const RotCall &c) {
     if (c.allclose_check)
         hipLaunchKernelGGL(rot_allclose_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, total, not_close, bt);
 
+    auto H = [&](size_t off) { return reinterpret_cast<_Float16 *>(ws + off); };
+    const PolarImages img{{H(L.img_x0), H(L.img_x1)}, {H(L.img_xt0), H(L.img_xt1)}, H(L.img_g), H(L.img_g2)};
     const bool has_alpha = c.alpha != 0.0f;
     const int alignment = c.alignment;
     const float alpha = c.alpha;
@@ -927,7 +1285,7 @@ int rotate_run(const RotCall &c) {
         } else {
             // M = Ac^T Bc:  M[i][j] = sum_r Ac[r][i] Bc[r][j];  R = U V^T = the orthogonal polar factor of M
             gemm(Operand{ac, p, 1}, Operand{bc, p, 1}, R, p, p, n, none, g);
-            if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, done, c.sweeps_out, g, false, false)) != MECHA_OK) return rc;
+            if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, done, c.sweeps_out, g, false, false, &img)) != MECHA_OK) return rc;
         }
         if (c.transform_out != nullptr) MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, R, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
         const float *src = ac;
@@ -953,12 +1311,12 @@ int rotate_run(const RotCall &c) {
             MECHA_CHECK_HIP(hipMemcpy2DAsync(qbt, pitch, bc, pitch, sizeof(float) * n * p, (size_t)count, hipMemcpyDeviceToDevice, s));
             // fully centred (the default): both wide-case matrices have the all-ones vector as their exact left null vector
             const bool deflate = c.centralization == 1.0f;
-            if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true)) != MECHA_OK) return rc;
+            if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true, &img)) != MECHA_OK) return rc;
             // T^T = Bc Qb =: P (n x n):  P[r][k] = sum_c Bc[r][c] Qb^T[k][c]
             gemm(Operand{bc, 1, p}, Operand{qbt, 1, p}, P, n, n, p, none, g);
             // N^T = P^T Ac (n x p):  N^T[k][i] = sum_r P[r][k] Ac[r][i];  N = U S W^T, Z := polar(N^T) = W U^T
             gemm(Operand{P, n, 1}, Operand{ac, p, 1}, z, n, p, n, none, g);
-            if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true)) != MECHA_OK) return rc;
+            if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true, &img)) != MECHA_OK) return rc;
         }
         if (c.transform_out != nullptr) {
             MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, qbt, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));

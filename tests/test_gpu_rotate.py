@@ -74,6 +74,7 @@ def test_rotate_vs_oracle(oracle, shape, cz):
     ta, tb = torch.from_numpy(a).cuda().to(torch.bfloat16), torch.from_numpy(b).cuda().to(torch.bfloat16)
     got, sweeps = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=cz, return_sweeps=True)
     rel = rotate_rel_error(oracle, a, b, got.cpu().numpy(), want, cz)
+    print(f"rotate {shape} centralization {cz}: relative error {rel:.3e}")
     assert rel <= 1e-3, (shape, cz, rel, sweeps)
     assert sweeps in (14, 40)          # polar steps enqueued: 14 for the solve of a tall key, 2 x (6 + 14) for a wide key's two
     # the transform is orthogonal on the rotated subspace: norms of centred rows are preserved (tall / square keys)
@@ -109,6 +110,7 @@ def test_rotate_sdxl_shapes_vs_oracle(oracle, shape, cz):
     ta, tb = torch.from_numpy(a).cuda().to(torch.bfloat16), torch.from_numpy(b).cuda().to(torch.bfloat16)
     got = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=cz).cpu().numpy()
     rel = rotate_rel_error(oracle, a, b, got, want, cz)
+    print(f"rotate {shape} centralization {cz}: relative error {rel:.3e}")
     assert rel <= 1e-3, (shape, cz, rel)
     n, p = oracle.rotate_shape_2d(shape)
     a2, g2, b2 = (x.reshape(n, p).astype(np.float64) for x in (a, got, b))
