@@ -130,6 +130,7 @@ struct GemmEpilogue {
     // gemm128h_kernel only (its epilogue knows nothing but these and axpy_a / axpy_b; C may be NULL there):
     _Float16 *sp, *spt;         // if set: the result / its transpose ALSO go out as split-fp16 images (that kernel's operand format)
     const _Float16 *axpy_img;   // the axpy term, read from its split image (22 of its 24 significand bits)
+    int h;                      // set by gemm_h: tells gemm_reduce_kernel whose epilogue to run
 };
 // the epilogue of key `key` of a batch: workspace pointers move by the key's workspace stride, `out` by its arena offset
 __device__ __forceinline__ GemmEpilogue epilogue_for_key(GemmEpilogue e, const Batch &bt, int key) {
@@ -406,19 +407,23 @@ __device__ __forceinline__ void gemm128_finish(f32x16 (&acc)[2][2], float *c, co
             }
     if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
-// gemm128h_kernel's: v = axpy_a * axpy_img + axpy_b * acc; fp32 C if given; the image `sp` (with the mirror tile of a symmetric
-// product) and the transpose's image `spt`.  M % 4 == 0 (images have rows of whole slots).
+// gemm128h_kernel's: v = axpy_a * axpy_img + axpy_b * acc (+ col_bias); then `out` in its dtype with the finite flag, or fp32 C if
+// given; the image `sp` (with the mirror tile of a symmetric product) and the transpose's image `spt`.  M % 4 == 0 (images have
+// rows of whole slots).
 __device__ __forceinline__ void gemm128h_finish(f32x16 (&acc)[2][2], float *c, const GemmEpilogue &ee, int64_t M, int64_t N, int64_t bm0, int64_t bn0,
                                                 int wm, int wn, int i, int kk, bool symmetric, bool mirror) {
     _Float16 *tsp = symmetric ? (mirror ? ee.sp : nullptr) : ee.spt;
     float *tc = (symmetric && mirror) ? c : nullptr;
+    bool bad = false;
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++)
+        for (int tn = 0; tn < 2; tn++) {
+            const int64_t col = bn0 + wn + 32 * tn + i;
+            const float bias = (ee.col_bias != nullptr && col < N) ? ee.col_bias[col] : 0.0f;
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
-                const int64_t row0 = bm0 + wm + 32 * tm + 8 * g4 + 4 * kk, col = bn0 + wn + 32 * tn + i;
+                const int64_t row0 = bm0 + wm + 32 * tm + 8 * g4 + 4 * kk;
                 if (row0 >= M || col >= N) continue;            // (whole groups: M % 4 == 0)
                 f32x4 v4;
 #pragma unroll
@@ -426,13 +431,22 @@ __device__ __forceinline__ void gemm128h_finish(f32x16 (&acc)[2][2], float *c, c
                     float v = acc[tm][tn][4 * g4 + j];
                     const int64_t at = split_at(row0 + j, col, N);
                     if (ee.axpy_img != nullptr) v = __builtin_fmaf(ee.axpy_a, split_load1(ee.axpy_img, at), ee.axpy_b * v);
-                    if (c != nullptr) c[(row0 + j) * N + col] = v;
+                    v += bias;
+                    if (ee.out != nullptr) {
+                        bad |= nonfinite_f32(v);
+                        const int64_t idx = ee.out_off + (row0 + j) * N + col;
+                        if (ee.out_dt == MECHA_BF16) store1<MECHA_BF16>(ee.out, idx, v);
+                        else if (ee.out_dt == MECHA_F16) store1<MECHA_F16>(ee.out, idx, v);
+                        else store1<MECHA_F32>(ee.out, idx, v);
+                    } else if (c != nullptr) c[(row0 + j) * N + col] = v;
                     if (ee.sp != nullptr) split_store1(ee.sp, at, v);
                     v4[j] = v;
                 }
                 if (tsp != nullptr) split_store4(tsp, split_at(col, row0, M), v4);
                 if (tc != nullptr) *reinterpret_cast<f32x4 *>(tc + col * M + row0) = v4;
             }
+        }
+    if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
 // symmetric: A and B are the same operand (C = X X^T, or G G of a symmetric G) and the epilogue is at most the axpy of a
@@ -693,14 +707,48 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
         const int64_t row = t / N, col = t - row * N;
         float s = 0.0f;
         for (int z = 0; z < n_slabs; z++) s += slabs[(int64_t)z * total + t];
-        if (e.sp != nullptr || e.spt != nullptr || e.axpy_img != nullptr) {          // a product of gemm128h_kernel
+        if (e.h) {                                              // a product of gemm128h_kernel: gemm128h_finish's steps
             if (e.axpy_img != nullptr) s = __builtin_fmaf(e.axpy_a, split_load1(e.axpy_img, split_at(row, col, N)), e.axpy_b * s);
-            if (C != nullptr) C[t] = s;
+            if (e.col_bias != nullptr) s += e.col_bias[col];
+            if (e.out != nullptr) {
+                bad |= nonfinite_f32(s);
+                if (e.out_dt == MECHA_BF16) store1<MECHA_BF16>(e.out, e.out_off + t, s);
+                else if (e.out_dt == MECHA_F16) store1<MECHA_F16>(e.out, e.out_off + t, s);
+                else store1<MECHA_F32>(e.out, e.out_off + t, s);
+            } else if (C != nullptr) C[t] = s;
             if (e.sp != nullptr) split_store1(e.sp, split_at(row, col, N), s);
             if (e.spt != nullptr) split_store1(e.spt, split_at(col, row, M), s);
         } else gemm_store(e, C, N, row, col, s, bad);
     }
     if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
+}
+
+// The centred matrices of a tall key straight as images (gemm128h_kernel's operands): Ac (n x p: the application's left operand)
+// and the transposes Ac^T, Bc^T (p x n: A^T B contracts over the rows).  64 x 64 tiles through LDS; n % 8 == 0, p % 8 == 0.
+__global__ __launch_bounds__(256) void rot_center_img_kernel(const void *a, const void *b, int dt, int64_t n, int64_t p, const float *a_mean,
+                                                             const float *b_mean, _Float16 *ac_img, _Float16 *act_img, _Float16 *bct_img, Batch bt) {
+    __shared__ float ta[64][65], tb[64][65];
+    const int key = blockIdx.z;
+    const int64_t base = key_off(bt, key);
+    a_mean = key_ptr(a_mean, bt, key); b_mean = key_ptr(b_mean, bt, key);
+    ac_img = key_ptr(ac_img, bt, key); act_img = key_ptr(act_img, bt, key); bct_img = key_ptr(bct_img, bt, key);
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float am = c0 + tx < p ? a_mean[c0 + tx] : 0.0f, bm = c0 + tx < p ? b_mean[c0 + tx] : 0.0f;
+    for (int j = ty; j < 64; j += 4)
+        if (r0 + j < n && c0 + tx < p) {
+            const int64_t at = (r0 + j) * p + c0 + tx;
+            const float x = ld_any(dt, a, base + at) - am, y = ld_any(dt, b, base + at) - bm;       // (svd.py:69-70)
+            ta[j][tx] = x; tb[j][tx] = y;
+            split_store1(ac_img, split_at(r0 + j, c0 + tx, p), x);
+        }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4)
+        if (c0 + j < p && r0 + tx < n) {
+            const int64_t at = split_at(c0 + j, r0 + tx, n);
+            split_store1(act_img, at, ta[tx][j]);
+            split_store1(bct_img, at, tb[tx][j]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ polar factor
@@ -802,7 +850,9 @@ void gemm(Operand A, Operand B, float *C, int64_t M, int64_t N, int64_t K, const
 // C[m][n] = sum_k a[m][k] b[n][k] from the split-fp16 images of a (M x K) and b (N x K); M, N >= 256, K % 8 == 0.  Same slab
 // logic as gemm().  32-deep k-chunks, two in flight (measured best: 1.123 s against 1.149 s for MECHA_ROT_HK=16, one in flight,
 // on the 1071 SDXL keys).
-void gemm_h(const _Float16 *a, const _Float16 *b, float *C, int64_t M, int64_t N, int64_t K, const GemmEpilogue &e, const GemmCtx &g, bool symmetric = false) {
+void gemm_h(const _Float16 *a, const _Float16 *b, float *C, int64_t M, int64_t N, int64_t K, const GemmEpilogue &e_in, const GemmCtx &g, bool symmetric = false) {
+    GemmEpilogue e = e_in;
+    e.h = 1;
     static const int hk = [] { const char *v = getenv("MECHA_ROT_HK"); return v != nullptr && atoi(v) == 16 ? 16 : 32; }();
     const int count = g.bt.count;
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128) * count;
@@ -818,7 +868,7 @@ void gemm_h(const _Float16 *a, const _Float16 *b, float *C, int64_t M, int64_t N
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)(z * count)), block(256);
     float *dst = z == 1 ? C : g.slabs;
     const GemmEpilogue none{};
-    const int sym = (symmetric && z == 1 && M == N && e.spt == nullptr) ? 1 : 0;
+    const int sym = (symmetric && z == 1 && M == N && e.spt == nullptr && e.out == nullptr && e.col_bias == nullptr) ? 1 : 0;
     const HOperand A{a, 2 * K}, B{b, 2 * K};
 #define MECHA_GEMMH(HK_, D_) MECHA_LAUNCH(MK_ROT_GEMM, (gemm128h_kernel<HK_, D_>), grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none, sym)
     if (hk == 32) MECHA_GEMMH(32, 2);
@@ -1265,7 +1315,18 @@ int rotate_run(const RotCall &c) {
     const int64_t total = n * p;
     const int64_t cbw = (total + 255) / 256, cb_cap = count >= 64 ? 64 : 4096 / count;
     const unsigned cb = (unsigned)(cbw < cb_cap ? cbw : cb_cap);
-    hipLaunchKernelGGL(rot_center_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac, bc, bt);
+    // Tall keys in the common configuration (rotate onto b, no interpolation) never hold their centred matrices in fp32: the
+    // centring writes the three images its two big products read (A^T B and the application), on the split-fp16 kernel like the
+    // polar steps between them (measured on SDXL shapes: the same 1e-6 relative error against the fp64 oracle either way).
+    const char *prec_env = getenv("MECHA_ROT_PREC");
+    const bool tall_h = n >= p && c.alignment == 1 && c.alpha == 0.0f && c.transform_in == nullptr && p >= 256 && (n & 7) == 0 && (p & 7) == 0 &&
+                        !(prec_env != nullptr && strcmp(prec_env, "f32") == 0);
+    _Float16 *ac_img = reinterpret_cast<_Float16 *>(ac), *act_img = reinterpret_cast<_Float16 *>(bc), *bct_img = reinterpret_cast<_Float16 *>(y);
+    if (tall_h)
+        hipLaunchKernelGGL(rot_center_img_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)count), dim3(256), 0, s, c.a, c.b,
+                           c.in_dt, n, p, a_mean, b_mean, ac_img, act_img, bct_img, bt);
+    else
+        hipLaunchKernelGGL(rot_center_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac, bc, bt);
     if (c.allclose_check)
         hipLaunchKernelGGL(rot_allclose_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, total, not_close, bt);
 
@@ -1278,7 +1339,16 @@ int rotate_run(const RotCall &c) {
     GemmEpilogue fin{};                                         // + lerp(a_mean, b_mean, alignment), cast, finite flag  (svd.py:85-86)
     fin.col_bias = t_mean; fin.out = c.out; fin.out_dt = c.out_dt; fin.flags = c.flags;
     int rc;
-    if (n >= p) {
+    if (tall_h) {
+        float *R = F(L.m0), *twin = F(L.m1), *G = F(L.m2), *G2 = F(L.m3);
+        // M = Ac^T Bc as (rows of Ac^T) x (rows of Bc^T);  R = its polar factor;  out = Ac R + mean as (rows of Ac) x (rows of R^T)
+        gemm_h(act_img, bct_img, R, p, p, n, none, g);
+        if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, done, c.sweeps_out, g, false, false, &img)) != MECHA_OK) return rc;
+        if (c.transform_out != nullptr) MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, R, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
+        MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)((p + 63) / 64), (unsigned)count), dim3(256), 0, s, R, img.x[0],
+                     img.xt[0], p, p, (int)SPLIT_PLAIN, scal, bt);
+        gemm_h(ac_img, img.xt[0], nullptr, n, p, p, fin, g);
+    } else if (n >= p) {
         float *R = F(L.m0), *twin = F(L.m1), *G = F(L.m2), *G2 = F(L.m3);
         if (c.transform_in != nullptr) {
             MECHA_CHECK_HIP(hipMemcpyAsync(R, c.transform_in, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
