@@ -723,15 +723,18 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
     if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
-// The centred matrices of a tall key straight as images (gemm128h_kernel's operands): Ac (n x p: the application's left operand)
-// and the transposes Ac^T, Bc^T (p x n: A^T B contracts over the rows).  64 x 64 tiles through LDS; n % 8 == 0, p % 8 == 0.
+// The centred matrices straight as images (gemm128h_kernel's operands), 64 x 64 tiles through LDS; n % 8 == 0, p % 8 == 0:
+//   always  Ac (n x p: left operand of the application) and Ac^T (p x n);
+//   tall keys: Bc^T (A^T B contracts over the rows);  wide keys: Bc (n x p) and Bc in fp32 (the first polar solve's input).
 __global__ __launch_bounds__(256) void rot_center_img_kernel(const void *a, const void *b, int dt, int64_t n, int64_t p, const float *a_mean,
-                                                             const float *b_mean, _Float16 *ac_img, _Float16 *act_img, _Float16 *bct_img, Batch bt) {
+                                                             const float *b_mean, _Float16 *ac_img, _Float16 *act_img, _Float16 *bct_img, _Float16 *bc_img,
+                                                             float *bc_f32, Batch bt) {
     __shared__ float ta[64][65], tb[64][65];
     const int key = blockIdx.z;
     const int64_t base = key_off(bt, key);
     a_mean = key_ptr(a_mean, bt, key); b_mean = key_ptr(b_mean, bt, key);
-    ac_img = key_ptr(ac_img, bt, key); act_img = key_ptr(act_img, bt, key); bct_img = key_ptr(bct_img, bt, key);
+    ac_img = key_ptr(ac_img, bt, key); act_img = key_ptr(act_img, bt, key); bct_img = key_ptr(bct_img, bt, key); bc_img = key_ptr(bc_img, bt, key);
+    bc_f32 = key_ptr(bc_f32, bt, key);
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float am = c0 + tx < p ? a_mean[c0 + tx] : 0.0f, bm = c0 + tx < p ? b_mean[c0 + tx] : 0.0f;
@@ -741,14 +744,27 @@ __global__ __launch_bounds__(256) void rot_center_img_kernel(const void *a, cons
             const float x = ld_any(dt, a, base + at) - am, y = ld_any(dt, b, base + at) - bm;       // (svd.py:69-70)
             ta[j][tx] = x; tb[j][tx] = y;
             split_store1(ac_img, split_at(r0 + j, c0 + tx, p), x);
+            if (bc_img != nullptr) split_store1(bc_img, split_at(r0 + j, c0 + tx, p), y);
+            if (bc_f32 != nullptr) bc_f32[at] = y;
         }
     __syncthreads();
     for (int j = ty; j < 64; j += 4)
         if (c0 + j < p && r0 + tx < n) {
             const int64_t at = split_at(c0 + j, r0 + tx, n);
             split_store1(act_img, at, ta[tx][j]);
-            split_store1(bct_img, at, tb[tx][j]);
+            if (bct_img != nullptr) split_store1(bct_img, at, tb[tx][j]);
         }
+}
+// img = the image of x - y (both n x p fp32), every key of the batch
+__global__ __launch_bounds__(256) void rot_diff_img_kernel(const float *x, const float *y, _Float16 *img, int64_t n, int64_t p, Batch bt) {
+    const int key = blockIdx.y;
+    x = key_ptr(x, bt, key); y = key_ptr(y, bt, key); img = key_ptr(img, bt, key);
+    const int64_t groups = n * p / 4;                           // four consecutive values of one row (p % 8 == 0)
+    for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * 256) {
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(x + 4 * gi) - *reinterpret_cast<const f32x4 *>(y + 4 * gi);
+        const int64_t row = 4 * gi / p, col = 4 * gi - row * p;
+        split_store4(img, split_at(row, col, p), d);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ polar factor
@@ -1203,7 +1219,7 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
 
 // Private workspace of one key, as offsets from its start; the same for every key of a shape.
 struct RotLayout {
-    size_t scal, part, a_mean, b_mean, t_mean, ac, bc, y, slabs, m0, m1, m2, m3, m4, m5, m6, m7, img_x0, img_x1, img_xt0, img_xt1, img_g, img_g2, total;
+    size_t scal, part, a_mean, b_mean, t_mean, ac, bc, y, slabs, m0, m1, m2, m3, m4, m5, m6, m7, img_x0, img_x1, img_xt0, img_xt1, img_g, img_g2, img_q, img_qt, total;
     size_t slab_floats;
 };
 RotLayout rot_layout(int64_t n, int64_t p, int count) {
@@ -1232,6 +1248,7 @@ RotLayout rot_layout(int64_t n, int64_t p, int count) {
         L.m0 = fl(n * p); L.m1 = fl(n * p); L.m2 = fl(n * p);
         L.m3 = fl(n * n); L.m4 = fl(n * n); L.m5 = fl(n * n); L.m6 = fl(n * n); L.m7 = fl(n * n);
         L.img_x0 = fl(n * p); L.img_x1 = fl(n * p); L.img_xt0 = fl(n * p); L.img_xt1 = fl(n * p); L.img_g = fl(n * n); L.img_g2 = fl(n * n);
+        L.img_q = fl(n * p); L.img_qt = fl(n * p);              // the first solve's result and its transpose, kept across the second
     }
     L.total = up256(cursor);
     return L;
@@ -1319,12 +1336,17 @@ int rotate_run(const RotCall &c) {
     // centring writes the three images its two big products read (A^T B and the application), on the split-fp16 kernel like the
     // polar steps between them (measured on SDXL shapes: the same 1e-6 relative error against the fp64 oracle either way).
     const char *prec_env = getenv("MECHA_ROT_PREC");
-    const bool tall_h = n >= p && c.alignment == 1 && c.alpha == 0.0f && c.transform_in == nullptr && p >= 256 && (n & 7) == 0 && (p & 7) == 0 &&
-                        !(prec_env != nullptr && strcmp(prec_env, "f32") == 0);
-    _Float16 *ac_img = reinterpret_cast<_Float16 *>(ac), *act_img = reinterpret_cast<_Float16 *>(bc), *bct_img = reinterpret_cast<_Float16 *>(y);
-    if (tall_h)
-        hipLaunchKernelGGL(rot_center_img_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)count), dim3(256), 0, s, c.a, c.b,
-                           c.in_dt, n, p, a_mean, b_mean, ac_img, act_img, bct_img, bt);
+    const bool plain = c.alignment == 1 && c.alpha == 0.0f && c.transform_in == nullptr && (n & 7) == 0 && (p & 7) == 0 &&
+                       !(prec_env != nullptr && strcmp(prec_env, "f32") == 0);
+    const bool tall_h = plain && n >= p && p >= 256, wide_h = plain && n < p && n >= 256;
+    _Float16 *ac_img = reinterpret_cast<_Float16 *>(ac), *bx_img = reinterpret_cast<_Float16 *>(bc), *act_img = reinterpret_cast<_Float16 *>(y);
+    const dim3 tile_grid((unsigned)((p + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)count);
+    if (tall_h)             // bx_img: Bc^T
+        hipLaunchKernelGGL(rot_center_img_kernel, tile_grid, dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac_img, act_img, bx_img,
+                           (_Float16 *)nullptr, (float *)nullptr, bt);
+    else if (wide_h)        // bx_img: Bc; its fp32 copy goes where the first polar solve works (m0)
+        hipLaunchKernelGGL(rot_center_img_kernel, tile_grid, dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac_img, act_img, (_Float16 *)nullptr,
+                           bx_img, F(L.m0), bt);
     else
         hipLaunchKernelGGL(rot_center_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac, bc, bt);
     if (c.allclose_check)
@@ -1342,12 +1364,39 @@ int rotate_run(const RotCall &c) {
     if (tall_h) {
         float *R = F(L.m0), *twin = F(L.m1), *G = F(L.m2), *G2 = F(L.m3);
         // M = Ac^T Bc as (rows of Ac^T) x (rows of Bc^T);  R = its polar factor;  out = Ac R + mean as (rows of Ac) x (rows of R^T)
-        gemm_h(act_img, bct_img, R, p, p, n, none, g);
+        gemm_h(act_img, bx_img, R, p, p, n, none, g);
         if ((rc = polar_newton_schulz(R, twin, G, G2, p, p, scal, done, c.sweeps_out, g, false, false, &img)) != MECHA_OK) return rc;
         if (c.transform_out != nullptr) MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, R, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
         MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)((p + 63) / 64), (unsigned)count), dim3(256), 0, s, R, img.x[0],
                      img.xt[0], p, p, (int)SPLIT_PLAIN, scal, bt);
         gemm_h(ac_img, img.xt[0], nullptr, n, p, p, fin, g);
+    } else if (wide_h) {
+        // The wide case (below) on the split kernel, every product from images:
+        //   Qb^T = polar(Bc);  P = Bc Qb as (rows of Bc) x (rows of Qb^T), kept as the image of P^T;  N^T = P^T Ac as (rows of P^T) x
+        //   (rows of Ac^T);  Z = polar(N^T);  out = x + (x Z^T - x Qb) Qb^T + mean with x = Ac:  D = x (Z - Qb^T)^T as (rows of x) x
+        //   (rows of Z - Qb^T) -- one product instead of two, the difference taken in fp32 before it is split --, then (rows of D) x
+        //   (rows of Qb), the pass-through x read back from its image.
+        float *qbt = F(L.m0), *z = F(L.m1), *twin = F(L.m2), *G = F(L.m3), *G2 = F(L.m4);
+        _Float16 *q_img = H(L.img_q), *qt_img = H(L.img_qt), *pt_img = img.g2, *zq_img = img.x[0], *d_img = img.g;
+        const bool deflate = c.centralization == 1.0f;
+        if ((rc = polar_newton_schulz(qbt, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true, &img)) != MECHA_OK) return rc;
+        MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, tile_grid, dim3(256), 0, s, qbt, q_img, qt_img, n, p, (int)SPLIT_PLAIN, scal, bt);
+        GemmEpilogue ep{};
+        ep.spt = pt_img;
+        gemm_h(bx_img, q_img, nullptr, n, n, p, ep, g);
+        gemm_h(pt_img, act_img, z, n, p, n, none, g);
+        if ((rc = polar_newton_schulz(z, twin, G, G2, n, p, scal, done, c.sweeps_out, g, deflate, true, &img)) != MECHA_OK) return rc;
+        if (c.transform_out != nullptr) {
+            MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, qbt, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+            MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out + n * p, z, sizeof(float) * n * p, hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL(rot_diff_img_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, z, qbt, zq_img, n, p, bt);
+        GemmEpilogue ed{};
+        ed.sp = d_img;
+        gemm_h(ac_img, zq_img, nullptr, n, n, p, ed, g);
+        GemmEpilogue ef = fin;
+        ef.axpy_img = ac_img; ef.axpy_a = 1.0f; ef.axpy_b = 1.0f;
+        gemm_h(d_img, qt_img, nullptr, n, p, n, ef, g);
     } else if (n >= p) {
         float *R = F(L.m0), *twin = F(L.m1), *G = F(L.m2), *G2 = F(L.m3);
         if (c.transform_in != nullptr) {
