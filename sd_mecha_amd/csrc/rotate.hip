@@ -1175,7 +1175,11 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
         steps += easy.n;
         // has every singular value arrived?  G of the current X, its distance from the identity, one word per key
         const GemmEpilogue none{};
-        gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g, true);
+        if (split_ok) {
+            MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)((r + 63) / 64), (unsigned)count), dim3(256), 0, g.s, cur,
+                         img->x[ib], (_Float16 *)nullptr, r, c, (int)SPLIT_PLAIN, scal, g.bt);
+            gemm_h(img->x[ib], img->x[ib], G, r, r, c, none, g, true);
+        } else gemm(Operand{cur, 1, c}, Operand{cur, 1, c}, G, r, r, c, none, g, true);
         gram_norms(G, r, scal, g);
         // |G - I|_F^2 = sum (sigma^2 - 1)^2: 1e-9 r allows an rms deviation of 1.6e-5 per singular value; 1e-13 r^2 is the
         // rounding floor of the fp32 Gram matrix itself

@@ -23,6 +23,9 @@ from sd_mecha_amd import merge_methods as mm  # noqa: E402
 from sd_mecha_amd.shapes import load_manifest, numel  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+# the batched rotate's products run as three fp16 MFMA products each (split-fp16 images, rotate.hip gemm128h_kernel): a third of
+# the dense f16 peak (~2.5 PFLOP/s) in fp32-equivalent flops
+SPLIT_F16_PEAK_TFLOPS = 2500.0 / 3
 F16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA peak
 
 
@@ -46,16 +49,22 @@ def polar_step_flops(r, c):
     return 2 * r * r * c * f + 2 * r * r * r * f + 2 * r * r * c
 
 
+def rotate_on_split_kernel(n, p):
+    """rotate.hip rotate_run: which keys run on the split-fp16 kernel at alignment 1 / alpha 0"""
+    return n % 8 == 0 and p % 8 == 0 and min(n, p) >= 256
+
+
 def rotate_flops_run(n, p, wide_keys_through_long_schedule=0.0):
-    """GEMM flops of one key on the batched path.  Tall: A^T B, 14 polar steps on p x p, the application.  Wide: two polar
-    solves of 6 steps + the Gram matrix of the convergence test (+ 14 steps for the given
-    fraction of keys), five n x n x p products."""
+    """GEMM flops of one key on the batched path (fp32-equivalent: a product counts once, however many MFMA passes it takes).
+    Tall: A^T B, 14 polar steps on p x p, the application.  Wide: two polar solves of 6 steps + the Gram matrix of the
+    convergence test (+ 14 steps for the given fraction of keys), and four n x n x p products on the split kernel
+    (x (Z - Qb^T)^T is one product there), five on the fp32 one."""
     if n >= p:
         return 4 * n * p * p + 14 * polar_step_flops(p, p)
     nt = -(-n // 128)
     f = (nt + 1) / (2 * nt) if n >= 256 else 1.0
     per_solve = 6 * polar_step_flops(n, p) + 2 * n * n * p * f + wide_keys_through_long_schedule * 14 * polar_step_flops(n, p)
-    return 10 * n * n * p + 2 * per_solve
+    return (8 if rotate_on_split_kernel(n, p) else 10) * n * n * p + 2 * per_solve
 
 
 def run_rotate_batched(args, device):
@@ -77,9 +86,9 @@ def run_rotate_batched(args, device):
         groups.setdefault(mm.rotate_shape_2d(shape), []).append(i)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     per_group = []
-    t_total, flops_total = 0.0, 0
+    t_total, flops_total, flops_split = 0.0, 0, 0
     for rep in range(args.warmup + 1):
-        per_group, t_total, flops_total = [], 0.0, 0
+        per_group, t_total, flops_total, flops_split = [], 0.0, 0, 0
         for (n, p), idx in sorted(groups.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1]):
             offs = torch.tensor([layout.offsets[i] for i in idx], dtype=torch.int64).to(device)
             flags = torch.zeros(len(idx), dtype=torch.int32, device=device)
@@ -106,6 +115,7 @@ def run_rotate_batched(args, device):
                               **({"converged_after_short_schedule": short_ok} if n < p else {})})
             t_total += dt
             flops_total += fl
+            flops_split += fl if rotate_on_split_kernel(n, p) else 0
     done_bytes = layout.payload_elems * 2 * 3
     return {
         "metric": "merged state-dict GB/s", "value": round(done_bytes / t_total / 1e9, 3), "unit": "GB/s", "n_gpus": 1,
@@ -113,10 +123,14 @@ def run_rotate_batched(args, device):
         "config": {"workload": "sdxl_rotate", "description": "SDXL svd.rotate(a, b, alignment=1.0, alpha=0.0), every >=2-D key of 2 random-init bf16 checkpoints, "
                    "bf16 out, batched by 2-D shape (one launch sequence per shape)", "keys": len(keys), "key_stride": args.key_stride, "shape_groups": len(groups)},
         "seconds": round(t_total, 3), "keys_per_second": round(len(keys) / t_total, 2),
-        "roofline": {"bound": "mfma", "kernel": "rotate_gemm_f32mfma", "achieved": round(flops_total / t_total / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(flops_total / t_total / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "algorithmic_flops": flops_total, "note": "GEMM flops actually run (short polar schedule where a key's convergence word allowed it) over the "
-                     "wall time of all launch sequences, norms / centring / reductions included"},
+        "roofline": {"bound": "mfma", "kernel": "rotate_gemm_split_f16_mfma", "achieved": round(flops_total / t_total / 1e12, 2), "peak": round(SPLIT_F16_PEAK_TFLOPS, 1),
+                     "unit": "TFLOP/s", "frac": round(flops_total / t_total / 1e12 / SPLIT_F16_PEAK_TFLOPS, 4), "traffic": None,
+                     "algorithmic_flops": flops_total, "flops_on_split_kernel_frac": round(flops_split / max(flops_total, 1), 4),
+                     "f32_mfma_peak": F32_MFMA_PEAK_TFLOPS,
+                     "note": "fp32-equivalent GEMM flops actually run (short polar schedule where a key's convergence word allowed it) over the wall time of "
+                     "all launch sequences, norms / centring / image conversions / reductions included; peak = dense f16 MFMA / 3 (every product is three "
+                     "f16 MFMA products on split-fp16 operands); keys the split kernel does not take (a side < 256 or not a multiple of 8) run on "
+                     "v_mfma_f32_32x32x2_f32"},
         "groups": per_group[:16],
     }
 
