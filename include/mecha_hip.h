@@ -305,6 +305,20 @@ int mecha_rotate_ex(const void *a, const void *b, void *out, int64_t n_rows, int
                     float centralization, int alignment, float alpha, const float *transform_in, float *transform_out,
                     void *workspace, size_t workspace_bytes, int *sweeps_out, uint32_t *flags, void *stream);
 int mecha_allclose_half(const void *a, const void *b, int64_t numel, int in_dtype, uint32_t *not_close, void *stream);
+/* truncate_rank, exact mode (reference sd_mecha/extensions/builtin/merge_methods/svd.py:89-143 with
+ * use_approximate_basis=False: u[:, :r] * s[:r] @ vh[:r] of torch.linalg.svd(a.flatten(start_dim=1))): the best rank-`rank`
+ * approximation of one key, n_rows x n_cols row-major.  By Eckart-Young that matrix is A P with P the orthogonal projector on the
+ * `rank` leading eigenvectors of the smaller Gram matrix W; P = (I + sign(W - tau I)) / 2 for any tau between the rank-th and the
+ * next eigenvalue, sign() = the polar factor rotate's solver computes from matrix products alone, and tau comes from a bisection on
+ * the eigenvalue count (q + trace sign) / 2, one polar solve per trial (DESIGN.md "truncate_rank").  0 < rank < min(n_rows, n_cols):
+ * the reference's early-outs (svd.py:99-100 keys of < 2 dimensions, :111-116 rank >= max -> a, rank 0 -> zeros) stay in the host
+ * shim.  The approximate-basis mode (svd.py:126-127, a seeded random sketch) approximates this same matrix and has no parity
+ * target of its own; the host shim runs this entry point for both.  SYNCHRONISES `stream` once per trial (two doubles come back);
+ * *trials_out (HOST int, may be NULL) = polar solves run (typically 8-16).  Singular values below ~3e-4 of the largest are under the
+ * fp32 resolution of W: a cut among them keeps the largest count <= rank that could be resolved. */
+size_t mecha_truncate_rank_workspace_bytes(int64_t n_rows, int64_t n_cols);
+int mecha_truncate_rank(const void *a, void *out, int64_t n_rows, int64_t n_cols, int64_t rank, int in_dtype, int out_dtype, void *workspace,
+                        size_t workspace_bytes, int *trials_out, uint32_t *flags, void *stream);
 /* rotate for every key of ONE 2-D shape in one launch sequence (svd.py:10-86 per key; replaces one future per key,
  * merging.py:223-229, for a recipe rotate(model, model)): the keys lie in the per-model arenas at key_offsets[i] elements
  * (DEVICE int64[n_keys]); every GEMM, norm and centring launch covers all keys (the key index is a grid dimension), each

@@ -425,6 +425,23 @@ def orthogonal_procrustes(a2: np.ndarray, b2: np.ndarray):
     return "full", u @ vh
 
 
+def truncate_rank(a, rank: int = 8):
+    """svd.py:89-143 with use_approximate_basis=False: u[:, :r] * s[:r] @ vh[:r] of the SVD of a.flatten(start_dim=1) (fp64 here;
+    the reference runs LAPACK in the input's precision)."""
+    a = _f32(a)
+    if a.ndim < 2:                                              # svd.py:99-100
+        return a
+    a2 = a.reshape(a.shape[0], -1).astype(np.float64)           # svd.py:110
+    max_rank = min(a2.shape)
+    r = min(max(round(rank), 0), max_rank)                      # svd.py:111-112
+    if r == max_rank:
+        return a
+    if r == 0:
+        return np.zeros_like(a)
+    u, s, vh = np.linalg.svd(a2, full_matrices=False)
+    return ((u[:, :r] * s[:r]) @ vh[:r]).reshape(a.shape).astype(np.float32)   # svd.py:143
+
+
 def rotate(a, b, alignment: float = 1.0, alpha: float = 0.0, centralization: float = 1.0, return_transform: bool = False):
     """svd.py:10-86 at alignment in {-1, 0, 1} -- the in-scope configurations."""
     a, b = _f32(a), _f32(b)

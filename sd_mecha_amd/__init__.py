@@ -63,6 +63,7 @@ cast = merge_method(_mm.cast, reuse_outputs=False)
 omit_non_finite = merge_method(_mm.omit_non_finite, reuse_outputs=False)
 fallback = merge_method(_fallback, identifier="fallback", lazy=("a", "default"), reuse_outputs=False)
 rotate = merge_method(_mm.rotate, lazy=("a", "b"), cache_factory=lambda: _collections.defaultdict(dict))   # svd.py:10
+truncate_rank = merge_method(_mm.truncate_rank, cache_factory=dict)   # svd.py:89
 lora_merge = merge_method(_mm.lora_merge)
 lora_delta = merge_method(_mm.lora_delta)
 

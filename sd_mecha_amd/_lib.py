@@ -95,6 +95,8 @@ SIGNATURES = {
     "mecha_rotate_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "mecha_rotate": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_f, c_p, c_sz, c_p, c_p, c_p]),
     "mecha_rotate_transform_floats": (c_i64, [c_i64, c_i64]),
+    "mecha_truncate_rank_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "mecha_truncate_rank": (c_i, [c_p, c_p, c_i64, c_i64, c_i64, c_i, c_i, c_p, c_sz, c_p, c_p, c_p]),
     "mecha_rotate_ex": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_f, c_i, c_f, c_p, c_p, c_p, c_sz, c_p, c_p, c_p]),
     "mecha_allclose_half": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p]),
     "mecha_batched_rotate_workspace_bytes": (c_sz, [c_i64, c_i64, c_i]),

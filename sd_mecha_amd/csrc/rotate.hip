@@ -1476,6 +1476,135 @@ int rotate_run(const RotCall &c) {
     return MECHA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ truncate_rank
+// Best rank-r approximation of a key (svd.py:89-143, exact mode: u[:, :r] s[:r] vh[:r] of the full SVD).  By Eckart-Young it is
+// A P (or P A on the smaller side), P the orthogonal projector on the r leading eigenvectors of the Gram matrix W = A^T A (A A^T).
+// No factor of the SVD is needed on its own: with a threshold tau between the r-th and (r+1)-th eigenvalue,
+//     P = (I + sign(W - tau I)) / 2,     sign(S) = the polar factor of the symmetric S,
+// and the polar factor is what polar_newton_schulz computes with products alone.  tau is found by bisection on
+//     count(tau) = #{eigenvalues > tau} = (q + trace sign(W - tau I)) / 2,
+// one polar solve per trial (q x q), driven from the host (two doubles read back per trial).  A trial whose threshold lands
+// within fp32 resolution of an eigenvalue leaves that eigenvalue's sign unconverged (|sign|_F^2 < q): it still steers the
+// bisection but is never accepted.  If the r-th and (r+1)-th eigenvalues cannot be told apart at all (a tie, or both below the
+// Gram matrix's fp32 floor ~1e-7 |W|: singular values under ~3e-4 of the largest) the projector of the largest count <= r found
+// is used -- the reference's own answer is arbitrary inside such a cluster.
+__global__ __launch_bounds__(256) void trunc_load_kernel(const void *a, int dt, int64_t numel, float *a32, uint32_t *flags) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float v = ld_any(dt, a, i);
+        bad |= nonfinite_f32(v);
+        a32[i] = v;
+    }
+    if (bad && flags != nullptr) atomicOr(flags, MECHA_FLAG_INPUT_NONFINITE);
+}
+// x = w - tau I  (q x q)
+__global__ __launch_bounds__(256) void trunc_shift_kernel(const float *w, float *x, int64_t q, float tau) {
+    const int64_t total = q * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) x[i] = w[i] - ((i / q == i % q) ? tau : 0.0f);
+}
+// out[0] = trace(x) (one block, fp64)
+__global__ __launch_bounds__(256) void trunc_trace_kernel(const float *x, int64_t q, double *out) {
+    __shared__ double sh[4];
+    double s0 = 0.0;
+    for (int64_t i = threadIdx.x; i < q; i += 256) s0 += (double)x[i * q + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s0 += __shfl_down(s0, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s0;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// x = -I
+__global__ __launch_bounds__(256) void trunc_minus_identity_kernel(float *x, int64_t q) {
+    const int64_t total = q * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) x[i] = (i / q == i % q) ? -1.0f : 0.0f;
+}
+
+struct TruncLayout { size_t scal, a32, w, x, twin, g, g2, best, slabs, img[6], total, slab_floats; bool images; };
+TruncLayout trunc_layout(int64_t m, int64_t n) {
+    TruncLayout L{};
+    const size_t q = (size_t)(m < n ? m : n);
+    size_t cursor = 0;
+    auto fl = [&](size_t count_) { const size_t o = cursor; cursor = up256(cursor + count_ * sizeof(float)); return o; };
+    L.scal = cursor; cursor = up256(cursor + 8 * sizeof(double));
+    L.a32 = fl((size_t)m * (size_t)n);
+    L.w = fl(q * q); L.x = fl(q * q); L.twin = fl(q * q); L.g = fl(q * q); L.g2 = fl(q * q); L.best = fl(q * q);
+    L.slab_floats = 2 * q * q > SLAB_FLOATS ? SLAB_FLOATS : (2 * q * q < 4096 ? 4096 : 2 * q * q);
+    L.slabs = fl(L.slab_floats);
+    L.images = q >= 256 && (q & 7) == 0;
+    for (int i = 0; i < 6; i++) L.img[i] = L.images ? fl(q * q) : 0;
+    L.total = up256(cursor);
+    return L;
+}
+constexpr int TRUNC_MAX_TRIALS = 48;
+
+int truncate_rank_run(const void *a, void *out, int64_t m, int64_t n, int64_t rank, int in_dt, int out_dt, void *workspace, size_t workspace_bytes,
+                      int *trials_out, uint32_t *flags, void *stream) {
+    const TruncLayout L = trunc_layout(m, n);
+    MECHA_REQUIRE(workspace != nullptr && workspace_bytes >= L.total && mecha_aligned16(workspace),
+                  "truncate_rank workspace too small or unaligned: need %zu bytes, got %zu", L.total, workspace_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    auto H = [&](size_t off) { return reinterpret_cast<_Float16 *>(ws + off); };
+    double *scal = reinterpret_cast<double *>(ws + L.scal);
+    float *a32 = F(L.a32), *W = F(L.w), *X = F(L.x), *twin = F(L.twin), *G = F(L.g), *G2 = F(L.g2), *best = F(L.best);
+    const PolarImages img{{H(L.img[0]), H(L.img[1])}, {H(L.img[2]), H(L.img[3])}, H(L.img[4]), H(L.img[5])};
+    const GemmCtx g{ONE_KEY, F(L.slabs), L.slab_floats, s};
+    const bool left = m <= n;                                   // the Gram matrix of the smaller side
+    const int64_t q = left ? m : n, total = m * n, qq = q * q;
+    const unsigned eb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), qb = (unsigned)((qq + 255) / 256 < 1024 ? (qq + 255) / 256 : 1024);
+    hipLaunchKernelGGL(trunc_load_kernel, dim3(eb), dim3(256), 0, s, a, in_dt, total, a32, flags);
+    const GemmEpilogue none{};
+    if (left) gemm(Operand{a32, 1, n}, Operand{a32, 1, n}, W, m, m, n, none, g, true);          // W = A A^T
+    else gemm(Operand{a32, n, 1}, Operand{a32, n, 1}, W, n, n, m, none, g, true);               // W = A^T A
+    // trace W = sum of the eigenvalues, |W|_F >= the largest: the r-th eigenvalue lies in [0, min(|W|_F, trace / r)]
+    hipLaunchKernelGGL(rot_zero_scal_kernel, dim3(1), dim3(64), 0, s, scal, 2, ONE_KEY);
+    hipLaunchKernelGGL(rot_sumsq_kernel, dim3(qb), dim3(256), 0, s, W, qq, scal, ONE_KEY);
+    hipLaunchKernelGGL(trunc_trace_kernel, dim3(1), dim3(256), 0, s, W, q, scal + 3);
+    double host[2];
+    MECHA_CHECK_HIP(hipMemcpyAsync(host, scal + 2, sizeof(host), hipMemcpyDeviceToHost, s));
+    MECHA_CHECK_HIP(hipStreamSynchronize(s));
+    const double w_fro = sqrt(host[0]), w_trace = host[1];
+    hipLaunchKernelGGL(trunc_minus_identity_kernel, dim3(qb), dim3(256), 0, s, best, q);        // count 0: the projector on nothing
+    int64_t best_count = 0;
+    int trials = 0;
+    if (w_fro > 0.0 && w_fro == w_fro && w_fro < 1e300) {
+        // bisection on t = sqrt(tau) (the singular-value scale: eigenvalues of W span twice the orders of magnitude)
+        const double cap = w_trace / (double)rank < w_fro ? w_trace / (double)rank : w_fro;
+        double lo = 0.0, hi = sqrt(cap) * (1.0 + 1e-6);
+        const double hi0 = hi;
+        for (; trials < TRUNC_MAX_TRIALS && hi - lo > 1e-7 * hi0; ) {
+            const double t = 0.5 * (lo + hi);
+            trials++;
+            hipLaunchKernelGGL(trunc_shift_kernel, dim3(qb), dim3(256), 0, s, W, X, q, (float)(t * t));
+            int rc = polar_newton_schulz(X, twin, G, G2, q, q, scal, reinterpret_cast<uint32_t *>(scal + 4), nullptr, g, false, false, L.images ? &img : nullptr);
+            if (rc != MECHA_OK) return rc;
+            hipLaunchKernelGGL(rot_zero_scal_kernel, dim3(1), dim3(64), 0, s, scal, 2, ONE_KEY);
+            hipLaunchKernelGGL(rot_sumsq_kernel, dim3(qb), dim3(256), 0, s, X, qq, scal, ONE_KEY);
+            hipLaunchKernelGGL(trunc_trace_kernel, dim3(1), dim3(256), 0, s, X, q, scal + 3);
+            MECHA_CHECK_HIP(hipMemcpyAsync(host, scal + 2, sizeof(host), hipMemcpyDeviceToHost, s));
+            MECHA_CHECK_HIP(hipStreamSynchronize(s));
+            if (!(host[0] == host[0]) || !(host[1] == host[1])) break;       // NaN: non-finite input, flagged already
+            const bool converged = fabs(host[0] - (double)q) < 0.01;        // |sign|_F^2 = q when every eigenvalue reached +-1
+            const int64_t count = (int64_t)llround(0.5 * ((double)q + host[1]));
+            if (count > rank) lo = t; else hi = t;
+            if (converged && count <= rank && count > best_count) {
+                MECHA_CHECK_HIP(hipMemcpyAsync(best, X, sizeof(float) * qq, hipMemcpyDeviceToDevice, s));
+                best_count = count;
+            }
+            if (converged && count == rank) break;
+        }
+    }
+    if (trials_out) *trials_out = trials;
+    // out = A P = (A + A sign) / 2   (P A = (A + sign A) / 2 on the left)
+    GemmEpilogue fin{};
+    fin.axpy = a32; fin.axpy_a = 0.5f; fin.axpy_b = 0.5f; fin.out = out; fin.out_dt = out_dt; fin.flags = flags;
+    if (left) gemm(Operand{best, 1, m}, Operand{a32, n, 1}, nullptr, m, n, m, fin, g);          // C[i][j] = sum_k sign[i][k] A[k][j]
+    else gemm(Operand{a32, 1, n}, Operand{best, 1, n}, nullptr, m, n, n, fin, g);               // C[i][j] = sum_k A[i][k] sign[j][k]
+    MECHA_CHECK_HIP(hipGetLastError());
+    return MECHA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1535,6 +1664,25 @@ int mecha_batched_rotate(const void *a_arena, const void *b_arena, void *out_are
     RotCall c{a_arena, b_arena, out_arena, key_offsets, n_keys, n, p, in_dtype, out_dtype, centralization, alignment, alpha, nullptr, nullptr,
               workspace, workspace_bytes, nullptr, flags, true, stream};
     return rotate_run(c);
+}
+
+size_t mecha_truncate_rank_workspace_bytes(int64_t n_rows, int64_t n_cols) {
+    if (n_rows < 1) n_rows = 1;
+    if (n_cols < 1) n_cols = 1;
+    return trunc_layout(n_rows, n_cols).total;
+}
+
+// truncate_rank, exact mode (svd.py:89-143 with use_approximate_basis=False), of one key flattened to n_rows x n_cols
+// (a.flatten(start_dim=1), svd.py:110); 0 < rank < min(n_rows, n_cols) (the reference returns `a` or zeros outside, svd.py:111-116:
+// the caller's shortcut).  Synchronises the stream once per bisection trial; *trials_out (nullable) = polar solves run.
+int mecha_truncate_rank(const void *a, void *out, int64_t n_rows, int64_t n_cols, int64_t rank, int in_dtype, int out_dtype, void *workspace,
+                        size_t workspace_bytes, int *trials_out, uint32_t *flags, void *stream) {
+    MECHA_REQUIRE(a != nullptr && out != nullptr, "NULL tensor pointer");
+    MECHA_REQUIRE(n_rows >= 2 && n_cols >= 2, "truncate_rank needs a 2-D key with both sides >= 2 (got %lld x %lld)", (long long)n_rows, (long long)n_cols);
+    MECHA_REQUIRE(mecha_valid_dtype(in_dtype) && mecha_valid_dtype(out_dtype), "unknown dtype code");
+    MECHA_REQUIRE(rank > 0 && rank < (n_rows < n_cols ? n_rows : n_cols), "truncate_rank: rank must lie strictly between 0 and min(rows, cols) = %lld, got %lld",
+                  (long long)(n_rows < n_cols ? n_rows : n_cols), (long long)rank);
+    return truncate_rank_run(a, out, n_rows, n_cols, rank, in_dtype, out_dtype, workspace, workspace_bytes, trials_out, flags, stream);
 }
 
 // torch.allclose(a.half(), b.half()) of svd.py:46.  ORs 1 into *not_close (device word, zeroed by the caller) if any element differs.

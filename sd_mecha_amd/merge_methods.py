@@ -706,6 +706,40 @@ def rotate(a, b, alignment: float = 1.0, alpha=0.0, centralization: float = 1.0,
     return (out, sweeps.value) if return_sweeps else out
 
 
+def truncate_rank(a, rank: int = 8, use_approximate_basis: bool = True, approximate_basis_iters: int = 2, approximate_basis_seed=None, *,
+                  key=None, cache=None, out_dtype=None, flags=None, check_finite=True, return_trials: bool = False):
+    """truncate_rank (svd.py:89-143): the best rank-``rank`` approximation of ``a.flatten(start_dim=1)``, reshaped.  The MI355X path
+    computes the exact (Eckart-Young) matrix -- what the reference returns for ``use_approximate_basis=False`` -- for either value of
+    the flag: the reference's default is a randomised sketch of that same matrix (svd.py:126-127, :239-265; unseeded by default),
+    so it has no parity target of its own, and ``approximate_basis_iters`` / ``approximate_basis_seed`` only steer that sketch.
+    ``cache`` (svd.py:102-107, :118-142: the reference keeps u, s, vh in fp16 per key) is accepted and not used.  Early-outs as the
+    reference: keys of < 2 dimensions and ``rank >= min(shape)`` return ``a`` (svd.py:99-100, :113-114), ``rank <= 0`` zeros (:115-116)."""
+    a = _c(_resolve(a, key))
+    _check_inputs([a], "truncate_rank")
+    out_dt = out_dtype or torch.float32
+    if a.dim() < 2:
+        res = a if out_dt == a.dtype else cast(a, out_dt, key=key, flags=flags, check_finite=check_finite)
+        return (res, 0) if return_trials else res
+    m, n = a.shape[0], (a.numel() // a.shape[0] if a.shape[0] else 0)
+    max_rank = min(m, n)
+    target = min(max(round(rank), 0), max_rank)
+    if target == max_rank:
+        res = a if out_dt == a.dtype else cast(a, out_dt, key=key, flags=flags, check_finite=check_finite)
+        return (res, 0) if return_trials else res
+    if target == 0:
+        res = torch.zeros_like(a, dtype=out_dt)
+        return (res, 0) if return_trials else res
+    L = _lib.lib()
+    out = _out(a, out_dt)
+    ws = _workspace(L.mecha_truncate_rank_workspace_bytes(m, n), a.device)
+    trials = ctypes.c_int(0)
+    fl = _Flags(a.device, flags, check_finite)
+    _lib.check(L.mecha_truncate_rank(a.data_ptr(), out.data_ptr(), m, n, int(target), _DT[a.dtype], _DT[out.dtype], ws.data_ptr(), ws.numel(),
+                                     ctypes.byref(trials), fl.ptr, _stream()), "mecha_truncate_rank")
+    fl.finish(key)
+    return (out, trials.value) if return_trials else out
+
+
 def lora_delta(up: torch.Tensor, down: torch.Tensor, alpha=None, target_shape=None, *, out_dtype=None) -> torch.Tensor:
     """LoraAlgorithm.compose / compose_alpha (lycoris.py:226-263): (up @ down) * (alpha / r or 1), reshaped."""
     return lora_merge(None, [(up, down, alpha, 1.0)], target_shape, out_dtype=out_dtype)

@@ -240,6 +240,31 @@ def gen_rotate(out):
     out["n_cases"] = np.array(case)
 
 
+def gen_truncate_rank(out):
+    """svd.truncate_rank (svd.py:89-143) with use_approximate_basis=False: the Eckart-Young rank-r matrix, on full-rank Gaussian
+    keys (every singular-value gap well above fp32 resolution) in bf16 / fp32, 2-D, conv-shaped (flatten(start_dim=1)) and 1-D;
+    plus the early-outs (rank >= max rank -> a, rank 0 -> zeros)."""
+    rng = np.random.default_rng(143)
+    case = 0
+    for shape, dtype, ranks in [((64, 48), "float32", (1, 8, 47)), ((24, 64), "bfloat16", (4, 23)), ((96, 96), "float32", (16, 64)),
+                                ((8, 4, 3, 3), "float32", (3,)), ((300, 272), "float32", (8, 100)), ((12,), "float32", (4,))]:
+        a = rand_half(rng, shape, dtype) if dtype != "float32" else torch.from_numpy(rng.normal(0, 0.02, size=shape).astype(np.float32))
+        pre = f"t{case}"
+        out[pre + "_a"] = bits(a)
+        out[pre + "_dtype"] = np.array(dtype)
+        out[pre + "_shape"] = np.array(shape)
+        out[pre + "_ranks"] = np.array(ranks)
+        for r in ranks:
+            res = svd.truncate_rank.__wrapped__(a.float(), rank=r, use_approximate_basis=False)
+            out[f"{pre}_out_rank{r}"] = bits(res.float())
+        if len(shape) >= 2:
+            full = min(shape[0], int(np.prod(shape[1:])))
+            assert torch.equal(svd.truncate_rank.__wrapped__(a.float(), rank=full, use_approximate_basis=False), a.float())
+            assert not svd.truncate_rank.__wrapped__(a.float(), rank=0, use_approximate_basis=False).any()
+        case += 1
+    out["n_cases"] = np.array(case)
+
+
 def gen_lora(out):
     rng = np.random.default_rng(16)
     cases = [((64, 8), (8, 48), (64, 48)), ((32, 8, 1, 1), (8, 16, 3, 3), (32, 16, 3, 3)), ((160, 8), (8, 192), (160, 192))]
@@ -655,7 +680,7 @@ def main():
     torch.set_num_threads(1)      # the goldens must not depend on torch's thread-chunked reduction tails
     only = set(sys.argv[1:])
     for name, fn in [("streaming", gen_streaming), ("alpha_tensor", gen_alpha_tensor), ("ties", gen_ties), ("dare", gen_dare), ("stock_dropout", gen_stock_dropout),
-                     ("rotate", gen_rotate), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_plans", gen_e2e_plans), ("e2e_mixed", gen_e2e_mixed), ("e2e_alias", gen_e2e_alias), ("e2e_lora", gen_e2e_lora), ("mecha_text", gen_mecha_text),
+                     ("rotate", gen_rotate), ("truncate_rank", gen_truncate_rank), ("lora", gen_lora), ("e2e", gen_e2e), ("e2e_plans", gen_e2e_plans), ("e2e_mixed", gen_e2e_mixed), ("e2e_alias", gen_e2e_alias), ("e2e_lora", gen_e2e_lora), ("mecha_text", gen_mecha_text),
                      ("configs", gen_configs)]:
         if only and name not in only:
             continue

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
 from conftest import load_golden  # noqa: E402
-from test_oracle_golden import ROTATE_EXTRA_CASES, f32_from_bits, rotate_case_undetermined, rotate_rel_error  # noqa: E402
+from test_oracle_golden import ROTATE_EXTRA_CASES, f32_from_bits, rotate_case_undetermined, rotate_rel_error, truncate_rank_cases  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -300,3 +300,71 @@ def test_full_config4_job_properties_and_sampled_keys(oracle):
                 assert rel <= 1e-3, (kind, k, o[k].shape, rel)
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+# ------------------------------------------------------------------ truncate_rank (svd.py:89-143, exact mode)
+def _rel(got, want):
+    return float(np.linalg.norm(got.astype(np.float64) - want.astype(np.float64))) / max(float(np.linalg.norm(want.astype(np.float64))), 1e-30)
+
+
+def test_truncate_rank_golden(oracle):
+    """Against the reference's own outputs (tests/golden/truncate_rank.npz): <= 1e-3 relative Frobenius error, in every input dtype
+    the key may arrive in; both values of use_approximate_basis run the exact path."""
+    import sd_mecha_amd as amd
+    n = 0
+    for name, a, r, want in truncate_rank_cases(oracle):
+        for dt in (torch.float32, torch.bfloat16):
+            ta = torch.from_numpy(a).cuda().to(dt)
+            if not torch.equal(ta.float().cpu(), torch.from_numpy(a)):
+                continue                                            # the golden input is not representable in this dtype
+            got, trials = amd.truncate_rank(ta, rank=r, use_approximate_basis=bool(n & 1), return_trials=True)
+            rel = _rel(got.cpu().numpy(), want)
+            print(f"truncate_rank {name} {dt}: relative error {rel:.3e} after {trials} polar solves")
+            assert got.dtype == torch.float32 and got.shape == ta.shape
+            assert rel <= 1e-3, (name, dt, rel, trials)
+            n += 1
+    assert n >= 10
+    x = torch.randn(6, 5, device="cuda")
+    assert torch.equal(amd.truncate_rank(x, rank=5), x) and torch.equal(amd.truncate_rank(x, rank=99), x)       # svd.py:113-114
+    assert not amd.truncate_rank(x, rank=0).any()                                                               # svd.py:115-116
+    assert torch.equal(amd.truncate_rank(x[0], rank=2), x[0])                                                   # svd.py:99-100
+    out = amd.truncate_rank(x.to(torch.bfloat16), rank=2, out_dtype=torch.bfloat16)
+    assert out.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("shape,rank", [((1280, 1280), 8), ((1280, 1280), 640), ((640, 2048), 64), ((320, 320, 3, 3), 32), ((5120, 1280), 128),
+                                        ((2048, 77), 16)])
+def test_truncate_rank_sdxl_shapes_vs_oracle(oracle, shape, rank):
+    """SDXL's shapes (conv keys flatten to out x (in kh kw), svd.py:110): against the fp64 oracle, and as properties -- the result has
+    rank `rank` exactly where its singular values say so, and the residual is orthogonal to it."""
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(89 + rank)
+    a = oracle.to_f32(oracle.from_f32(rng.normal(0, 0.02, size=shape).astype(np.float32), "bfloat16"), "bfloat16")
+    want = oracle.truncate_rank(a, rank)
+    got, trials = amd.truncate_rank(torch.from_numpy(a).cuda().to(torch.bfloat16), rank=rank, return_trials=True)
+    got = got.cpu().numpy()
+    rel = _rel(got, want)
+    print(f"truncate_rank {shape} rank {rank}: relative error {rel:.3e} after {trials} polar solves")
+    assert rel <= 1e-3, (shape, rank, rel, trials)
+    g2, a2 = got.reshape(shape[0], -1).astype(np.float64), a.reshape(shape[0], -1).astype(np.float64)
+    sv = np.linalg.svd(g2, compute_uv=False)
+    assert sv[rank] <= 1e-4 * sv[0] and sv[rank - 1] > 1e-2 * sv[0], (sv[rank - 1] / sv[0], sv[rank] / sv[0])
+    resid = a2 - g2
+    assert abs(np.vdot(resid, g2)) <= 1e-4 * np.linalg.norm(g2) ** 2                     # A - A_r is orthogonal to A_r
+
+
+def test_truncate_rank_low_rank_and_clustered_inputs(oracle):
+    """Inputs whose rank is below the request (the cut falls among zero singular values: the key comes back whole) and a spectrum
+    with a tight cluster away from the cut."""
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(7)
+    low = (rng.normal(size=(384, 12)) @ rng.normal(size=(12, 320))).astype(np.float32)
+    got = amd.truncate_rank(torch.from_numpy(low).cuda(), rank=40).cpu().numpy()
+    assert _rel(got, low) <= 1e-3
+    u, _ = np.linalg.qr(rng.normal(size=(300, 300)))
+    v, _ = np.linalg.qr(rng.normal(size=(260, 260)))
+    sv = np.concatenate([np.full(5, 3.0) * (1 + 1e-5 * np.arange(5)), np.linspace(1.0, 0.01, 255)])
+    a = ((u[:, :260] * sv) @ v.T).astype(np.float32)
+    for rank in (5, 20):
+        got = amd.truncate_rank(torch.from_numpy(a).cuda(), rank=rank).cpu().numpy()
+        assert _rel(got, oracle.truncate_rank(a, rank)) <= 1e-3, rank
