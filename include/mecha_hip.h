@@ -162,7 +162,9 @@ int mecha_add_difference_ties(const void *base, const void *const *models, int n
  * use a scratch array that is part of the library's device image (8 MiB per GPU the library runs on, held until the process
  * ends).  Limits: 1..8 models, numel <= 2^26 (every SDXL / FLUX key); beyond them the call fails with MECHA_ERR_ARG and a
  * message naming the limit.  Calls no hipMalloc / hipFree or allocating routine; the first call on a device looks the
- * array's address up (hipGetSymbolAddress).  Every call on a GPU shares that GPU's array (the call clears what must start
+ * array's address up (hipGetSymbolAddress: not a stream operation, so make that first call OUTSIDE graph capture -- one warm-up
+ * call per device; later calls only enqueue kernels and memsets, and with mecha_set_profiling off nothing else).  Every call on
+ * a GPU shares that GPU's array (the call clears what must start
  * at zero): calls that OVERLAP on one GPU -- two streams, two threads -- race; serialise them or use the workspace form. */
 int mecha_add_difference_ties_noalloc(const void *base, const void *const *models, int n_models, void *out,
                                       int64_t numel, int in_dtype, int out_dtype, double k, float alpha,

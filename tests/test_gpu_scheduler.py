@@ -33,6 +33,24 @@ def test_merge_matches_reference_on_gpu(toy_models, tmp_path, buffer):       # n
     check_against_reference(safetensors.torch.load_file(str(out)), "navg4")
 
 
+def test_truncate_rank_in_a_recipe(toy_models, oracle):                      # noqa: F811
+    """truncate_rank (svd.py:89-143) inside merge(): a + truncate_rank(b - a, rank) key by key (the per-key executor), against the
+    oracle's exact-mode result computed from the same bf16 inputs; keys of <= 1 dimension pass through (svd.py:99-100)."""
+    import safetensors.torch
+    import sd_mecha_amd as amd
+    m = [amd.model(p) for p in toy_models[:2]]
+    recipe = amd.add_difference(m[0], amd.truncate_rank(amd.subtract(m[1], m[0]), rank=3, use_approximate_basis=False), alpha=1.0)
+    res = amd.merge(recipe, merge_device="cuda", output_dtype=torch.float32)
+    a, b = (safetensors.torch.load_file(str(p)) for p in toy_models[:2])
+    for k in SHAPES:
+        af, bf = a[k].float().numpy(), b[k].float().numpy()
+        want = (af + oracle.truncate_rank(bf - af, 3)).reshape(af.shape)
+        got = res[k].cpu().numpy()
+        assert got.shape == want.shape, k
+        if want.size:
+            assert np.linalg.norm(got.astype(np.float64) - want) <= 1e-3 * max(np.linalg.norm(want), 1e-30), k
+
+
 def test_generic_path_runs_method_bodies_per_key(toy_models):               # noqa: F811
     """Recipes the fuser does not cover (here: a graph of primitives and a user-defined @merge_method) are evaluated key
     by key with the same bodies on device tensors; a graph of primitives must equal the fused pipeline bit for bit."""

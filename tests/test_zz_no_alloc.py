@@ -30,11 +30,13 @@ def _call_pair(L, _lib, n_models, numel, seed, k=0.2, alpha=1.0, dtype=torch.bfl
     got_thr = torch.zeros(n_models, dtype=torch.float32, device="cuda")
     got_flags = torch.zeros(1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # torch's own counter sees only torch's allocator; hipMemGetInfo's free bytes see a hipMalloc made inside the library too
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
     _lib.check(L.mecha_add_difference_ties_noalloc(base.data_ptr(), ptrs, n_models, got.data_ptr(), numel, code, code, k, alpha, 0,
                                                    got_thr.data_ptr(), got_flags.data_ptr(), stream), "allocation-free form")
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before
     assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n_models, numel)
     assert torch.equal(got_thr.view(torch.int32), want_thr.view(torch.int32))
     assert int(got_flags.item()) == int(want_flags.item()) == 0
@@ -50,6 +52,41 @@ def test_noalloc_matches_workspace_form_twice_in_a_row():
     _call_pair(L, _lib, 7, 640 * 640, seed=3, k=0.5, alpha=0.7)
     _call_pair(L, _lib, 1, 4096, seed=4)                                   # a key the sample pass solves whole
     _call_pair(L, _lib, 2, 3000, seed=5, dtype=torch.float16)
+
+
+def test_noalloc_under_graph_capture():
+    """The use the entry point is for: captured into a HIP graph (after one warm-up call outside capture, which looks the scratch
+    array's address up once per device -- not a capturable operation) and replayed on new inputs."""
+    from sd_mecha_amd import _lib
+    L = _lib.lib()
+    numel, n_models = 640 * 640 + 24, 3
+    g = torch.Generator(device="cuda").manual_seed(11)
+    base = torch.empty(numel, dtype=torch.bfloat16, device="cuda").normal_(0.0, 0.02, generator=g)
+    models = [torch.empty(numel, dtype=torch.bfloat16, device="cuda").normal_(0.0, 0.02, generator=g) for _ in range(n_models)]
+    ptrs = _lib.ptr_array([m.data_ptr() for m in models])
+    out = torch.empty(numel, dtype=torch.bfloat16, device="cuda")
+    flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def call():
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.mecha_add_difference_ties_noalloc(base.data_ptr(), ptrs, n_models, out.data_ptr(), numel, _lib.BF16, _lib.BF16, 0.2, 1.0, 0,
+                                                       None, flags.data_ptr(), stream), "allocation-free form")
+    call()                                                      # warm-up outside capture: the symbol lookup of the scratch array
+    torch.cuda.synchronize()
+    want = out.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for m in models:                                            # new inputs in the same buffers, then replay
+        m.normal_(0.0, 0.02, generator=g)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = out.clone()
+    call()
+    torch.cuda.synchronize()
+    assert torch.equal(replayed.view(torch.int16), out.view(torch.int16))
+    assert not torch.equal(replayed.view(torch.int16), want.view(torch.int16))
 
 
 def test_noalloc_non_finite_flag_and_oracle():
