@@ -83,6 +83,56 @@ __global__ __launch_bounds__(256) void rot_colsum_kernel(const void *a, const vo
     if (bad && flags != nullptr) atomicOr(flags, MECHA_FLAG_INPUT_NONFINITE);
 }
 
+// The same for p % 8 == 0 and 16-byte-aligned keys (every key of an arena), with 16-byte loads: a lane owns 8 consecutive
+// columns, a wave a row of 512, the block's four waves take every fourth row of the chunk.  The same pass evaluates
+// torch.allclose(a.half(), b.half()) (svd.py:46) when `not_close` is given -- both read a and b once, whole.
+// grid (ceil(p / 512), chunks, keys).
+template <int DT>
+__global__ __launch_bounds__(256) void rot_colsum8_kernel(const void *a, const void *b, int64_t n, int64_t p, int chunks, double *part /* [2][chunks][p] */,
+                                                          uint32_t *flags, uint32_t *not_close, Batch bt) {
+    __shared__ double sh[2][3][512];
+    const int key = blockIdx.z;
+    const int64_t base = key_off(bt, key);
+    part = key_ptr(part, bt, key);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 512 + 8 * lane;
+    const int64_t rows_per = (n + chunks - 1) / chunks;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = (r0 + rows_per < n) ? r0 + rows_per : n;
+    double sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sa[j] = 0.0; sb[j] = 0.0; }
+    bool bad = false, differ = false;
+    if (col < p) {
+        for (int64_t r = r0 + wave; r < r1; r += 4) {
+            float x[8], y[8];
+            load8<DT>(a, base + r * p + col, x);
+            load8<DT>(b, base + r * p + col, y);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                bad |= nonfinite_f32(x[j]) | nonfinite_f32(y[j]);
+                sa[j] += (double)x[j]; sb[j] += (double)y[j];
+                const float xh = (float)(_Float16)x[j], yh = (float)(_Float16)y[j];
+                differ |= !((xh == yh) || (__builtin_fabsf(xh - yh) <= 1e-8f + 1e-5f * __builtin_fabsf(yh)));
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { sh[0][wave - 1][8 * lane + j] = sa[j]; sh[1][wave - 1][8 * lane + j] = sb[j]; }
+    }
+    __syncthreads();
+    if (wave == 0 && col < p) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = 8 * lane + j;
+            part[((int64_t)0 * chunks + blockIdx.y) * p + col + j] = sa[j] + sh[0][0][c] + sh[0][1][c] + sh[0][2][c];
+            part[((int64_t)1 * chunks + blockIdx.y) * p + col + j] = sb[j] + sh[1][0][c] + sh[1][1][c] + sh[1][2][c];
+        }
+    }
+    if (bad && flags != nullptr) atomicOr(flags + key, MECHA_FLAG_INPUT_NONFINITE);
+    if (differ && not_close != nullptr) atomicOr(not_close + key, 1u);
+}
+
 __global__ __launch_bounds__(256) void rot_means_kernel(const double *part, int chunks, int64_t n, int64_t p, float cz, float t,
                                                         float *a_mean, float *b_mean, float *t_mean, Batch bt) {
     const int key = blockIdx.y;
@@ -1329,8 +1379,17 @@ int rotate_run(const RotCall &c) {
     if (!header) done = reinterpret_cast<uint32_t *>(scal + 4);
 
     const int chunks = (int)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
-    hipLaunchKernelGGL(rot_colsum_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)chunks, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p,
-                       chunks, part, c.flags, bt);
+    // (batched calls: arena offsets are multiples of 128 elements, so every key is as aligned as the arenas are)
+    const bool vec8 = (p & 7) == 0 && ((reinterpret_cast<uintptr_t>(c.a) | reinterpret_cast<uintptr_t>(c.b)) & 15u) == 0;
+    if (vec8) {
+        const dim3 cgrid((unsigned)((p + 511) / 512), (unsigned)chunks, (unsigned)count);
+        uint32_t *nc = c.allclose_check ? not_close : nullptr;
+        if (c.in_dt == MECHA_BF16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_BF16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
+        else if (c.in_dt == MECHA_F16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
+        else hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F32>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
+    } else
+        hipLaunchKernelGGL(rot_colsum_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)chunks, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p,
+                           chunks, part, c.flags, bt);
     hipLaunchKernelGGL(rot_means_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)count), dim3(256), 0, s, part, chunks, n, p, c.centralization,
                        (float)c.alignment, a_mean, b_mean, t_mean, bt);
     const int64_t total = n * p;
@@ -1353,7 +1412,7 @@ int rotate_run(const RotCall &c) {
                            bx_img, F(L.m0), bt);
     else
         hipLaunchKernelGGL(rot_center_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac, bc, bt);
-    if (c.allclose_check)
+    if (c.allclose_check && !vec8)
         hipLaunchKernelGGL(rot_allclose_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, total, not_close, bt);
 
     auto H = [&](size_t off) { return reinterpret_cast<_Float16 *>(ws + off); };

@@ -624,6 +624,11 @@ class HipBackend:
         fl_all = torch.zeros(max(len(order), 1), dtype=torch.int32, device=self.device)
         pos = 0
         if flat:
+            # ORDER MATTERS: the batched lerp computes EVERY element of the arena (its segment table only attributes the flag
+            # words), so it also writes lerp values into the output regions of the 2-D keys; the rotate launches below run later
+            # on the same stream and overwrite those regions completely (GEMM epilogues, rot_same_kernel).  Keep this launch
+            # first.  (test_gpu_rotate.py::test_batched_rotate_through_merge mixes 1-D and 2-D keys in one wave and would see
+            # lerp values in a 2-D key if the order changed.)
             segs = upload([[layout.offsets[i], layout.numels[i]] for i in flat])
             _lib.check(L.mecha_batched_weighted_sum(arenas[0].data_ptr(), arenas[1].data_ptr(), out.data_ptr(), segs.data_ptr(), len(flat),
                                                     layout.total_elems, in_dt, out_dt, alpha, fl_all.data_ptr(), stream), "batched lerp (rotate, ndim <= 1)")

@@ -231,6 +231,36 @@ def test_batched_rotate_ill_conditioned_wide_keys(oracle, tmp_path, monkeypatch,
         assert rel <= 1e-3, (k, rel)
 
 
+@pytest.mark.parametrize("n,p", [(64, 256), (256, 1024)])
+def test_rotate_borderline_conditioned_wide_keys(oracle, monkeypatch, n, p):
+    """Fully centred wide keys whose b has a few singular values at 1e-3 .. 5e-3 of the largest -- just past what the optimistic
+    6-step schedule is made for (POLAR_EASY_L), where its on-device convergence test decides: the default run (optimistic phase,
+    deflated null direction) must agree with the 14-step-only run (MECHA_ROT_POLAR=long) and with the fp64 oracle, on both GEMM
+    paths (64 rows: fp32 kernel; 256 rows: split-fp16 kernel)."""
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(n)
+    for tail in ((1e-3, 2e-3, 5e-3), (3e-3,), (8e-3, 9e-3)):
+        u, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        v, _ = np.linalg.qr(rng.normal(size=(p, n)))
+        sv = np.linspace(1.0, 0.3, n)
+        sv[-len(tail):] = tail
+        a = oracle.to_f32(oracle.from_f32(rng.normal(0, 0.02, size=(n, p)).astype(np.float32), "bfloat16"), "bfloat16")
+        b = ((u * sv) @ v.T * 0.5).astype(np.float32)                      # fp32 input: the small singular values survive
+        want = oracle.rotate(a, b, alignment=1.0, alpha=0.0, centralization=1.0)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        monkeypatch.delenv("MECHA_ROT_POLAR", raising=False)
+        got = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=1.0).cpu().numpy()
+        monkeypatch.setenv("MECHA_ROT_POLAR", "long")
+        long = amd.rotate(ta, tb, alignment=1.0, alpha=0.0, centralization=1.0).cpu().numpy()
+        monkeypatch.delenv("MECHA_ROT_POLAR")
+        rel = rotate_rel_error(oracle, a, b, got, want, 1.0)
+        rel_long = rotate_rel_error(oracle, a, b, long, want, 1.0)
+        between = np.linalg.norm(got.astype(np.float64) - long) / np.linalg.norm(long)
+        print(f"rotate {n} x {p}, tail {tail}: default {rel:.3e}, long schedule {rel_long:.3e}, default vs long {between:.3e}")
+        assert rel <= 1e-3 and rel_long <= 1e-3, (tail, rel, rel_long)
+        assert between <= 1e-3, (tail, between)
+
+
 def test_full_config4_job_properties_and_sampled_keys(oracle):
     """BASELINE config 4 at FULL size: rotate(A, B, alignment=1, alpha=0) over every key of two SDXL-shaped bf16 checkpoints
     through merge() (files on tmpfs -> batched plan -> one fp32 file), checked where no CPU SVD of the whole job is affordable:
