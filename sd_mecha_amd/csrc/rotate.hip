@@ -133,6 +133,46 @@ __global__ __launch_bounds__(256) void rot_colsum8_kernel(const void *a, const v
     if (differ && not_close != nullptr) atomicOr(not_close + key, 1u);
 }
 
+// Keys with very few columns (3 x 3 convolutions flatten to (out * in) x 9, svd.py:49-53): rot_colsum_kernel would use p of its 64
+// column lanes.  Here a thread owns whole rows -- p consecutive values each, neighbouring threads neighbouring rows -- and keeps
+// the p column sums in registers.  grid (1, chunks, keys); P_MAX = 16.
+constexpr int COLSUM_SMALL_P = 16;
+__global__ __launch_bounds__(256) void rot_colsum_small_kernel(const void *a, const void *b, int dt, int64_t n, int p, int chunks, double *part, uint32_t *flags,
+                                                               Batch bt) {
+    __shared__ double sh[2][4][COLSUM_SMALL_P];
+    const int key = blockIdx.z;
+    const int64_t base = key_off(bt, key);
+    part = key_ptr(part, bt, key);
+    const int64_t rows_per = (n + chunks - 1) / chunks;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = (r0 + rows_per < n) ? r0 + rows_per : n;
+    double sa[COLSUM_SMALL_P], sb[COLSUM_SMALL_P];
+#pragma unroll
+    for (int j = 0; j < COLSUM_SMALL_P; j++) { sa[j] = 0.0; sb[j] = 0.0; }
+    bool bad = false;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+#pragma unroll
+        for (int j = 0; j < COLSUM_SMALL_P; j++)
+            if (j < p) {
+                const float x = ld_any(dt, a, base + r * p + j), y = ld_any(dt, b, base + r * p + j);
+                bad |= nonfinite_f32(x) | nonfinite_f32(y);
+                sa[j] += (double)x; sb[j] += (double)y;
+            }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < COLSUM_SMALL_P; j++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sa[j] += __shfl_down(sa[j], off, 64); sb[j] += __shfl_down(sb[j], off, 64); }
+        if (lane == 0) { sh[0][wave][j] = sa[j]; sh[1][wave][j] = sb[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * COLSUM_SMALL_P) {
+        const int which = threadIdx.x / COLSUM_SMALL_P, j = threadIdx.x % COLSUM_SMALL_P;
+        if (j < p) part[((int64_t)which * chunks + blockIdx.y) * p + j] = sh[which][0][j] + sh[which][1][j] + sh[which][2][j] + sh[which][3][j];
+    }
+    if (bad && flags != nullptr) atomicOr(flags + key, MECHA_FLAG_INPUT_NONFINITE);
+}
+
 __global__ __launch_bounds__(256) void rot_means_kernel(const double *part, int chunks, int64_t n, int64_t p, float cz, float t,
                                                         float *a_mean, float *b_mean, float *t_mean, Batch bt) {
     const int key = blockIdx.y;
@@ -1387,7 +1427,10 @@ int rotate_run(const RotCall &c) {
         if (c.in_dt == MECHA_BF16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_BF16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
         else if (c.in_dt == MECHA_F16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
         else hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F32>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
-    } else
+    } else if (p <= COLSUM_SMALL_P)
+        hipLaunchKernelGGL(rot_colsum_small_kernel, dim3(1, (unsigned)chunks, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, (int)p, chunks, part,
+                           c.flags, bt);
+    else
         hipLaunchKernelGGL(rot_colsum_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)chunks, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p,
                            chunks, part, c.flags, bt);
     hipLaunchKernelGGL(rot_means_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)count), dim3(256), 0, s, part, chunks, n, p, c.centralization,
