@@ -622,6 +622,9 @@ struct HOperand { const _Float16 *p; int64_t ms; };            // image base, ha
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // offset (in halves) of 16-byte slot `slot` (8 k-values) of row `row` in a plane (128 x HK halves)
+// The low plane keeps row r where the high plane keeps row r ^ H_LO_FLIP (the row 64 bytes away): the 8 lanes one ds_write_b128
+// cycle serves hold the high AND low parts of the same rows, and both planes start at the same bank.
+template <int HK> constexpr int H_LO_FLIP = 32 / HK;
 template <int HK> __device__ __forceinline__ int h_slot(int row, int slot) {
     const int sw = HK == 16 ? ((row >> 3) & 1) : ((row >> 2) & 3);
     return row * HK + ((slot ^ sw) << 3);
@@ -648,7 +651,7 @@ template <int HK> __device__ __forceinline__ void h_tile_store(const HTileRegs<H
     const int tid = threadIdx.x, u = tid % LPR;
 #pragma unroll
     for (int h = 0; h < HK / 8; h++)
-        *reinterpret_cast<u32x4_t *>(lds + (u & 1) * H_PLANE + h_slot<HK>(tid / LPR + RPP * h, u >> 1)) = t.v[h];
+        *reinterpret_cast<u32x4_t *>(lds + (u & 1) * H_PLANE + h_slot<HK>((tid / LPR + RPP * h) ^ ((u & 1) * H_LO_FLIP<HK>), u >> 1)) = t.v[h];
 }
 
 // D: chunks of register prefetch.  The operand loads come from L2 or beyond at ~2 us under this kernel's own load (measured:
@@ -710,8 +713,9 @@ __global__ __launch_bounds__(256, (HK == 16 && D == 1) ? 3 : 2) void gemm128h_ke
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const int oa = h_slot<HK>(wm + 32 * t + i, 2 * s + kk), ob = h_slot<HK>(wn + 32 * t + i, 2 * s + kk);
-                    ah[t] = *reinterpret_cast<const f16x8 *>(pa + oa); al[t] = *reinterpret_cast<const f16x8 *>(pa + H_PLANE + oa);
-                    bh[t] = *reinterpret_cast<const f16x8 *>(pb + ob); bl[t] = *reinterpret_cast<const f16x8 *>(pb + H_PLANE + ob);
+                    const int oal = h_slot<HK>((wm + 32 * t + i) ^ H_LO_FLIP<HK>, 2 * s + kk), obl = h_slot<HK>((wn + 32 * t + i) ^ H_LO_FLIP<HK>, 2 * s + kk);
+                    ah[t] = *reinterpret_cast<const f16x8 *>(pa + oa); al[t] = *reinterpret_cast<const f16x8 *>(pa + H_PLANE + oal);
+                    bh[t] = *reinterpret_cast<const f16x8 *>(pb + ob); bl[t] = *reinterpret_cast<const f16x8 *>(pb + H_PLANE + obl);
                 }
 #pragma unroll
                 for (int tm = 0; tm < 2; tm++)
