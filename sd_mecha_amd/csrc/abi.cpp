@@ -21,7 +21,7 @@ double g_prof_ms[MK_COUNT];
 long long g_prof_launches[MK_COUNT];
 const char *const g_prof_names[MK_COUNT] = {
     "streaming_ew", "ties_tile_index", "ties_hist1", "ties_hist2", "ties_hist3", "ties_scan", "ties_merge",
-    "reduce_partial", "reduce_finish", "reduce_apply", "reduce_fixup", "lora_mfma", "rotate_gemm_f32mfma", "rotate_gram_norms",
+    "reduce_partial", "reduce_finish", "reduce_apply", "reduce_fixup", "lora_mfma", "rotate_gemm_mfma", "rotate_gram_norms",
     "ties_sample", "ties_count", "ties_resolve", "ties_fixup"};
 thread_local ProfRecord t_current;
 }  // namespace

@@ -182,7 +182,7 @@ def run_rotate(args, device):
             "config": {"workload": "sdxl_rotate", "description": "SDXL svd.rotate(a, b, alignment=1.0, alpha=0.0) per >=2-D key of 2 random-init bf16 checkpoints, bf16 out",
                        "keys": len(sweeps_all), "key_stride": args.key_stride, "threads": args.threads, "streams": args.threads},
             "seconds": round(t_total, 3), "keys_per_second": round(len(sweeps_all) / t_total, 2),
-            "roofline": {"bound": "mfma", "kernel": "rotate_gemm_f32mfma", "achieved": round(flops / t_total / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "rotate_gemm_mfma", "achieved": round(flops / t_total / 1e12, 2),
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / t_total / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "algorithmic_flops": flops,
                          "note": "achieved = algorithmic GEMM flops over WALL time of the whole job (kernels of several keys overlap: no per-kernel timers)"},
@@ -207,7 +207,7 @@ def run_rotate(args, device):
         del a, b, out
     kernels = _lib.profile_read()
     _lib.profile_enable(False)
-    gemm_ms = kernels.get("rotate_gemm_f32mfma", (0.0, 1))[0]
+    gemm_ms = kernels.get("rotate_gemm_mfma", (0.0, 1))[0]
     jac_ms = kernels.get("rotate_gram_norms", (0.0, 1))[0]
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
     return {
@@ -216,7 +216,7 @@ def run_rotate(args, device):
         "config": {"workload": "sdxl_rotate", "description": "SDXL svd.rotate(a, b, alignment=1.0, alpha=0.0) per >=2-D key of 2 random-init bf16 checkpoints, bf16 out",
                    "keys": len(sweeps_all), "key_stride": args.key_stride, "keys_skipped_too_large": skipped},
         "seconds": round(t_total, 3), "keys_per_second": round(len(sweeps_all) / t_total, 2),
-        "roofline": {"bound": "mfma", "kernel": "rotate_gemm_f32mfma", "achieved": round(achieved, 2) if achieved else None,
+        "roofline": {"bound": "mfma", "kernel": "rotate_gemm_mfma", "achieved": round(achieved, 2) if achieved else None,
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
                      "traffic": None, "algorithmic_flops": flops, "kernel_ms_total": round(gemm_ms, 2)},
         "newton_schulz": {"norms_ms_total": round(jac_ms, 2), "iterations_mean": round(sum(sweeps_all) / max(len(sweeps_all), 1), 2),
@@ -269,6 +269,12 @@ def run_lora(args, device):
     ms, launches = kernels.get("lora_mfma", (0.0, 1))
     per_step_ms = ms / args.steps
     achieved = flops / (per_step_ms * 1e-3) / 1e12 if per_step_ms else None
+    traffic, traffic_note = None, None
+    for name in ("r03_hbm_traffic.json",):                      # PMC counters of this same command, collected under rocprofv3 (profiles/README.md)
+        f = ROOT / "profiles" / name
+        if f.exists() and args.key_stride == 1 and (n_nets, rank) == (16, 32):
+            e = json.loads(f.read_text()).get("sdxl_lora", {}).get("lora_mfma", {})
+            traffic, traffic_note = e.get("hbm_bytes_per_launch"), e.get("_note")
     return {
         "metric": "merged state-dict GB/s", "value": round(moved / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
@@ -276,7 +282,7 @@ def run_lora(args, device):
                    "keys": len(job), "key_stride": args.key_stride, "bytes_per_step": moved},
         "roofline": {"bound": "hbm", "kernel": "lora_mfma", "achieved": round(moved / (per_step_ms * 1e-3) / 1e9, 1) if per_step_ms else None,
                      "peak": 8000.0, "unit": "GB/s", "frac": round(moved / (per_step_ms * 1e-3) / 1e9 / 8000.0, 4) if per_step_ms else None,
-                     "traffic": None, "kernel_ms_per_step": round(per_step_ms, 3),
+                     "traffic": traffic, "traffic_note": traffic_note, "kernel_ms_per_step": round(per_step_ms, 3),
                      "mfma_TFLOPs": round(achieved, 2) if achieved else None, "mfma_frac_of_dense_f16_peak": round(achieved / F16_MFMA_PEAK_TFLOPS, 4) if achieved else None,
                      "note": "rank-32 reconstruction has 2*32/(2*2) = 16 flop per output byte: far below the MFMA ridge, so HBM bounds it"},
         "kernels": {k: {"ms_total": round(v[0], 2), "launches": v[1]} for k, v in kernels.items()},
