@@ -78,10 +78,11 @@ __device__ __forceinline__ f32x16 mfma16(u16x8 a, u16x8 b, f32x16 c) {
 __device__ __forceinline__ void load4(int dt, bool vec, const void *p, int64_t i, int valid, float (&v)[4]) {
     if (vec) {
         if (dt == MECHA_F32) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p) + i);
+            // (non-temporal: the base and output tiles are touched once; the factors, re-read by every tile of a key, keep the L2)
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p) + i));
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
-            const u16x4 t = *reinterpret_cast<const u16x4 *>(reinterpret_cast<const uint16_t *>(p) + i);
+            const u16x4 t = __builtin_nontemporal_load(reinterpret_cast<const u16x4 *>(reinterpret_cast<const uint16_t *>(p) + i));
 #pragma unroll
             for (int q = 0; q < 4; q++) v[q] = (dt == MECHA_BF16) ? bf16_bits_to_f32(t[q]) : f16_bits_to_f32(t[q]);
         }
@@ -94,12 +95,12 @@ __device__ __forceinline__ void load4(int dt, bool vec, const void *p, int64_t i
 __device__ __forceinline__ void store4(int dt, bool vec, void *p, int64_t i, int valid, const float (&v)[4]) {
     if (vec) {
         if (dt == MECHA_F32) {
-            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p) + i) = f32x4{v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p) + i));
         } else {
             u16x4 t;
 #pragma unroll
             for (int q = 0; q < 4; q++) t[q] = (uint16_t)((dt == MECHA_BF16) ? f32_to_bf16_bits(v[q]) : f32_to_f16_bits(v[q]));
-            *reinterpret_cast<u16x4 *>(reinterpret_cast<uint16_t *>(p) + i) = t;
+            __builtin_nontemporal_store(t, reinterpret_cast<u16x4 *>(reinterpret_cast<uint16_t *>(p) + i));
         }
     } else {
 #pragma unroll
