@@ -43,6 +43,11 @@ struct Batch {
     const int64_t *offs;
     const uint32_t *skip;
 };
+// Slots of a key's block of 8 doubles (`scal`): 0-1 Gram norms, 2 sum of squares, 3 trace (truncate_rank), 4 the done word of a
+// single key, 5 the bit patterns of max |a| and max |b| (two uint32), 6 the image scales t_a, t_b (two floats: powers of two that
+// bring the centred matrices' entries to <= 2, so that their split-fp16 images cannot overflow whatever the weights' range), 7 the
+// float 1 / t_a.
+constexpr int ROT_SCAL_AMAX = 5, ROT_SCAL_T = 6, ROT_SCAL_INV_TA = 7;
 template <typename T> __device__ __forceinline__ T *key_ptr(T *p, const Batch &bt, int key) {
     return p == nullptr ? nullptr : reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(p)) + (int64_t)key * bt.ws_bytes);
 }
@@ -89,11 +94,13 @@ __global__ __launch_bounds__(256) void rot_colsum_kernel(const void *a, const vo
 // grid (ceil(p / 512), chunks, keys).
 template <int DT>
 __global__ __launch_bounds__(256) void rot_colsum8_kernel(const void *a, const void *b, int64_t n, int64_t p, int chunks, double *part /* [2][chunks][p] */,
-                                                          uint32_t *flags, uint32_t *not_close, Batch bt) {
+                                                          uint32_t *flags, uint32_t *not_close, double *scal, Batch bt) {
     __shared__ double sh[2][3][512];
     const int key = blockIdx.z;
     const int64_t base = key_off(bt, key);
     part = key_ptr(part, bt, key);
+    uint32_t *amax = reinterpret_cast<uint32_t *>(key_ptr(scal, bt, key) + ROT_SCAL_AMAX);      // bit patterns of max |a|, max |b| (zeroed by the host)
+    float ma = 0.0f, mb = 0.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 512 + 8 * lane;
     const int64_t rows_per = (n + chunks - 1) / chunks;
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(256) void rot_colsum8_kernel(const void *a, const v
             for (int j = 0; j < 8; j++) {
                 bad |= nonfinite_f32(x[j]) | nonfinite_f32(y[j]);
                 sa[j] += (double)x[j]; sb[j] += (double)y[j];
+                ma = __builtin_fmaxf(ma, __builtin_fabsf(x[j])); mb = __builtin_fmaxf(mb, __builtin_fabsf(y[j]));
                 const float xh = (float)(_Float16)x[j], yh = (float)(_Float16)y[j];
                 differ |= !((xh == yh) || (__builtin_fabsf(xh - yh) <= 1e-8f + 1e-5f * __builtin_fabsf(yh)));
             }
@@ -129,6 +137,9 @@ __global__ __launch_bounds__(256) void rot_colsum8_kernel(const void *a, const v
             part[((int64_t)1 * chunks + blockIdx.y) * p + col + j] = sb[j] + sh[1][0][c] + sh[1][1][c] + sh[1][2][c];
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ma = __builtin_fmaxf(ma, __shfl_xor(ma, off, 64)); mb = __builtin_fmaxf(mb, __shfl_xor(mb, off, 64)); }
+    if (lane == 0) { atomicMax(amax, __float_as_uint(ma)); atomicMax(amax + 1, __float_as_uint(mb)); }       // (non-negative floats order like their patterns)
     if (bad && flags != nullptr) atomicOr(flags + key, MECHA_FLAG_INPUT_NONFINITE);
     if (differ && not_close != nullptr) atomicOr(not_close + key, 1u);
 }
@@ -174,8 +185,22 @@ __global__ __launch_bounds__(256) void rot_colsum_small_kernel(const void *a, co
 }
 
 __global__ __launch_bounds__(256) void rot_means_kernel(const double *part, int chunks, int64_t n, int64_t p, float cz, float t,
-                                                        float *a_mean, float *b_mean, float *t_mean, Batch bt) {
+                                                        float *a_mean, float *b_mean, float *t_mean, double *scal, Batch bt) {
     const int key = blockIdx.y;
+    if (scal != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {         // the image scales (ROT_SCAL_T) from the largest magnitudes
+        double *sk = key_ptr(scal, bt, key);
+        const uint32_t *amax = reinterpret_cast<const uint32_t *>(sk + ROT_SCAL_AMAX);
+        float *ts = reinterpret_cast<float *>(sk + ROT_SCAL_T);
+        float tv[2];
+        for (int w = 0; w < 2; w++) {
+            const float m = __uint_as_float(amax[w]);
+            float e = (m > 0.0f && m < 3e38f) ? -ceilf(log2f(m)) : 0.0f;
+            e = e < -100.0f ? -100.0f : (e > 100.0f ? 100.0f : e);
+            tv[w] = exp2f(e);
+        }
+        ts[0] = tv[0]; ts[1] = tv[1];
+        *reinterpret_cast<float *>(sk + ROT_SCAL_INV_TA) = 1.0f / tv[0];
+    }
     part = key_ptr(part, bt, key); a_mean = key_ptr(a_mean, bt, key); b_mean = key_ptr(b_mean, bt, key); t_mean = key_ptr(t_mean, bt, key);
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= p) return;
@@ -220,12 +245,13 @@ struct GemmEpilogue {
     // gemm128h_kernel only (its epilogue knows nothing but these and axpy_a / axpy_b; C may be NULL there):
     _Float16 *sp, *spt;         // if set: the result / its transpose ALSO go out as split-fp16 images (that kernel's operand format)
     const _Float16 *axpy_img;   // the axpy term, read from its split image (22 of its 24 significand bits)
+    const float *acc_scale;     // if set: one float per key, multiplied in after the axpy and before col_bias (1 / t_a of scaled images)
     int h;                      // set by gemm_h: tells gemm_reduce_kernel whose epilogue to run
 };
 // the epilogue of key `key` of a batch: workspace pointers move by the key's workspace stride, `out` by its arena offset
 __device__ __forceinline__ GemmEpilogue epilogue_for_key(GemmEpilogue e, const Batch &bt, int key) {
     e.minus = key_ptr(e.minus, bt, key); e.plus = key_ptr(e.plus, bt, key); e.col_bias = key_ptr(e.col_bias, bt, key);
-    e.axpy = key_ptr(e.axpy, bt, key); e.mix = key_ptr(e.mix, bt, key); e.sp = key_ptr(e.sp, bt, key); e.spt = key_ptr(e.spt, bt, key); e.axpy_img = key_ptr(e.axpy_img, bt, key);
+    e.axpy = key_ptr(e.axpy, bt, key); e.mix = key_ptr(e.mix, bt, key); e.sp = key_ptr(e.sp, bt, key); e.spt = key_ptr(e.spt, bt, key); e.axpy_img = key_ptr(e.axpy_img, bt, key); e.acc_scale = key_ptr(e.acc_scale, bt, key);
     e.out_off = key_off(bt, key);
     if (e.flags != nullptr) e.flags += key;
     return e;
@@ -504,6 +530,7 @@ __device__ __forceinline__ void gemm128h_finish(f32x16 (&acc)[2][2], float *c, c
                                                 int wm, int wn, int i, int kk, bool symmetric, bool mirror) {
     _Float16 *tsp = symmetric ? (mirror ? ee.sp : nullptr) : ee.spt;
     float *tc = (symmetric && mirror) ? c : nullptr;
+    const float scale = ee.acc_scale != nullptr ? *ee.acc_scale : 1.0f;
     bool bad = false;
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
@@ -521,7 +548,7 @@ __device__ __forceinline__ void gemm128h_finish(f32x16 (&acc)[2][2], float *c, c
                     float v = acc[tm][tn][4 * g4 + j];
                     const int64_t at = split_at(row0 + j, col, N);
                     if (ee.axpy_img != nullptr) v = __builtin_fmaf(ee.axpy_a, split_load1(ee.axpy_img, at), ee.axpy_b * v);
-                    v += bias;
+                    v = v * scale + bias;
                     if (ee.out != nullptr) {
                         bad |= nonfinite_f32(v);
                         const int64_t idx = ee.out_off + (row0 + j) * N + col;
@@ -803,6 +830,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
         for (int z = 0; z < n_slabs; z++) s += slabs[(int64_t)z * total + t];
         if (e.h) {                                              // a product of gemm128h_kernel: gemm128h_finish's steps
             if (e.axpy_img != nullptr) s = __builtin_fmaf(e.axpy_a, split_load1(e.axpy_img, split_at(row, col, N)), e.axpy_b * s);
+            if (e.acc_scale != nullptr) s *= *e.acc_scale;
             if (e.col_bias != nullptr) s += e.col_bias[col];
             if (e.out != nullptr) {
                 bad |= nonfinite_f32(s);
@@ -817,15 +845,19 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
     if (bad && e.flags != nullptr) atomicOr(e.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
-// The centred matrices straight as images (gemm128h_kernel's operands), 64 x 64 tiles through LDS; n % 8 == 0, p % 8 == 0:
+// The centred matrices, times the key's powers of two t_a / t_b (ROT_SCAL_T: entries <= 2 whatever the weights' range; the polar
+// factors do not see a scale, the application multiplies by 1 / t_a), straight as images (gemm128h_kernel's operands), 64 x 64
+// tiles through LDS; n % 8 == 0, p % 8 == 0:
 //   always  Ac (n x p: left operand of the application) and Ac^T (p x n);
 //   tall keys: Bc^T (A^T B contracts over the rows);  wide keys: Bc (n x p) and Bc in fp32 (the first polar solve's input).
 __global__ __launch_bounds__(256) void rot_center_img_kernel(const void *a, const void *b, int dt, int64_t n, int64_t p, const float *a_mean,
                                                              const float *b_mean, _Float16 *ac_img, _Float16 *act_img, _Float16 *bct_img, _Float16 *bc_img,
-                                                             float *bc_f32, Batch bt) {
+                                                             float *bc_f32, const double *scal, Batch bt) {
     __shared__ float ta[64][65], tb[64][65];
     const int key = blockIdx.z;
     const int64_t base = key_off(bt, key);
+    const float *ts = reinterpret_cast<const float *>(key_ptr(scal, bt, key) + ROT_SCAL_T);
+    const float sa = ts[0], sb = ts[1];                         // powers of two: the products below are exact
     a_mean = key_ptr(a_mean, bt, key); b_mean = key_ptr(b_mean, bt, key);
     ac_img = key_ptr(ac_img, bt, key); act_img = key_ptr(act_img, bt, key); bct_img = key_ptr(bct_img, bt, key); bc_img = key_ptr(bc_img, bt, key);
     bc_f32 = key_ptr(bc_f32, bt, key);
@@ -835,7 +867,7 @@ __global__ __launch_bounds__(256) void rot_center_img_kernel(const void *a, cons
     for (int j = ty; j < 64; j += 4)
         if (r0 + j < n && c0 + tx < p) {
             const int64_t at = (r0 + j) * p + c0 + tx;
-            const float x = ld_any(dt, a, base + at) - am, y = ld_any(dt, b, base + at) - bm;       // (svd.py:69-70)
+            const float x = (ld_any(dt, a, base + at) - am) * sa, y = (ld_any(dt, b, base + at) - bm) * sb;   // (svd.py:69-70), times t_a / t_b
             ta[j][tx] = x; tb[j][tx] = y;
             split_store1(ac_img, split_at(r0 + j, c0 + tx, p), x);
             if (bc_img != nullptr) split_store1(bc_img, split_at(r0 + j, c0 + tx, p), y);
@@ -1428,9 +1460,10 @@ int rotate_run(const RotCall &c) {
     if (vec8) {
         const dim3 cgrid((unsigned)((p + 511) / 512), (unsigned)chunks, (unsigned)count);
         uint32_t *nc = c.allclose_check ? not_close : nullptr;
-        if (c.in_dt == MECHA_BF16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_BF16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
-        else if (c.in_dt == MECHA_F16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
-        else hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F32>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, bt);
+        hipLaunchKernelGGL(rot_zero_scal_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s, scal, (int)ROT_SCAL_AMAX, bt);
+        if (c.in_dt == MECHA_BF16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_BF16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, scal, bt);
+        else if (c.in_dt == MECHA_F16) hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F16>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, scal, bt);
+        else hipLaunchKernelGGL(rot_colsum8_kernel<MECHA_F32>, cgrid, dim3(256), 0, s, c.a, c.b, n, p, chunks, part, c.flags, nc, scal, bt);
     } else if (p <= COLSUM_SMALL_P)
         hipLaunchKernelGGL(rot_colsum_small_kernel, dim3(1, (unsigned)chunks, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, (int)p, chunks, part,
                            c.flags, bt);
@@ -1438,7 +1471,7 @@ int rotate_run(const RotCall &c) {
         hipLaunchKernelGGL(rot_colsum_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)chunks, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p,
                            chunks, part, c.flags, bt);
     hipLaunchKernelGGL(rot_means_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)count), dim3(256), 0, s, part, chunks, n, p, c.centralization,
-                       (float)c.alignment, a_mean, b_mean, t_mean, bt);
+                       (float)c.alignment, a_mean, b_mean, t_mean, vec8 ? scal : (double *)nullptr, bt);
     const int64_t total = n * p;
     const int64_t cbw = (total + 255) / 256, cb_cap = count >= 64 ? 64 : 4096 / count;
     const unsigned cb = (unsigned)(cbw < cb_cap ? cbw : cb_cap);
@@ -1446,17 +1479,17 @@ int rotate_run(const RotCall &c) {
     // centring writes the three images its two big products read (A^T B and the application), on the split-fp16 kernel like the
     // polar steps between them (measured on SDXL shapes: the same 1e-6 relative error against the fp64 oracle either way).
     const char *prec_env = getenv("MECHA_ROT_PREC");
-    const bool plain = c.alignment == 1 && c.alpha == 0.0f && c.transform_in == nullptr && (n & 7) == 0 && (p & 7) == 0 &&
+    const bool plain = vec8 && c.alignment == 1 && c.alpha == 0.0f && c.transform_in == nullptr && (n & 7) == 0 && (p & 7) == 0 &&
                        !(prec_env != nullptr && strcmp(prec_env, "f32") == 0);
     const bool tall_h = plain && n >= p && p >= 256, wide_h = plain && n < p && n >= 256;
     _Float16 *ac_img = reinterpret_cast<_Float16 *>(ac), *bx_img = reinterpret_cast<_Float16 *>(bc), *act_img = reinterpret_cast<_Float16 *>(y);
     const dim3 tile_grid((unsigned)((p + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)count);
     if (tall_h)             // bx_img: Bc^T
         hipLaunchKernelGGL(rot_center_img_kernel, tile_grid, dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac_img, act_img, bx_img,
-                           (_Float16 *)nullptr, (float *)nullptr, bt);
+                           (_Float16 *)nullptr, (float *)nullptr, scal, bt);
     else if (wide_h)        // bx_img: Bc; its fp32 copy goes where the first polar solve works (m0)
         hipLaunchKernelGGL(rot_center_img_kernel, tile_grid, dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac_img, act_img, (_Float16 *)nullptr,
-                           bx_img, F(L.m0), bt);
+                           bx_img, F(L.m0), scal, bt);
     else
         hipLaunchKernelGGL(rot_center_kernel, dim3(cb, (unsigned)count), dim3(256), 0, s, c.a, c.b, c.in_dt, n, p, a_mean, b_mean, ac, bc, bt);
     if (c.allclose_check && !vec8)
@@ -1479,7 +1512,9 @@ int rotate_run(const RotCall &c) {
         if (c.transform_out != nullptr) MECHA_CHECK_HIP(hipMemcpyAsync(c.transform_out, R, sizeof(float) * p * p, hipMemcpyDeviceToDevice, s));
         MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, dim3((unsigned)((p + 63) / 64), (unsigned)((p + 63) / 64), (unsigned)count), dim3(256), 0, s, R, img.x[0],
                      img.xt[0], p, p, (int)SPLIT_PLAIN, scal, bt);
-        gemm_h(ac_img, img.xt[0], nullptr, n, p, p, fin, g);
+        GemmEpilogue ea = fin;
+        ea.acc_scale = reinterpret_cast<const float *>(scal + ROT_SCAL_INV_TA);          // the image of Ac holds t_a Ac
+        gemm_h(ac_img, img.xt[0], nullptr, n, p, p, ea, g);
     } else if (wide_h) {
         // The wide case (below) on the split kernel, every product from images:
         //   Qb^T = polar(Bc);  P = Bc Qb as (rows of Bc) x (rows of Qb^T), kept as the image of P^T;  N^T = P^T Ac as (rows of P^T) x
@@ -1506,6 +1541,7 @@ int rotate_run(const RotCall &c) {
         gemm_h(ac_img, zq_img, nullptr, n, n, p, ed, g);
         GemmEpilogue ef = fin;
         ef.axpy_img = ac_img; ef.axpy_a = 1.0f; ef.axpy_b = 1.0f;
+        ef.acc_scale = reinterpret_cast<const float *>(scal + ROT_SCAL_INV_TA);          // x and D both carry t_a
         gemm_h(d_img, qt_img, nullptr, n, p, n, ef, g);
     } else if (n >= p) {
         float *R = F(L.m0), *twin = F(L.m1), *G = F(L.m2), *G2 = F(L.m3);

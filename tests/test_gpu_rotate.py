@@ -261,6 +261,24 @@ def test_rotate_borderline_conditioned_wide_keys(oracle, monkeypatch, n, p):
         assert between <= 1e-3, (tail, between)
 
 
+@pytest.mark.parametrize("shape", [(512, 256), (256, 512), (256, 256)])
+@pytest.mark.parametrize("scale", [3e5, 1e-6])
+def test_rotate_extreme_magnitudes(oracle, shape, scale):
+    """Weights far outside fp16's range (|w| up to ~2.5e4 here; 65504 / 64 is where an unscaled split-fp16 image would overflow) and
+    far below it: the split-kernel path scales each key's centred matrices by a power of two first (ROT_SCAL_T), so the result
+    matches the oracle like any other key; inputs in fp32 so that the magnitudes are what they say."""
+    import sd_mecha_amd as amd
+    rng = np.random.default_rng(int(shape[0] + 10 * np.log10(scale)))
+    a = (rng.normal(0, 0.02, size=shape) * scale).astype(np.float32)
+    b = (rng.normal(0, 0.02, size=shape) * scale * 3).astype(np.float32)           # b on another scale than a
+    want = oracle.rotate(a, b, alignment=1.0, alpha=0.0, centralization=1.0)
+    got = amd.rotate(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), alignment=1.0, alpha=0.0, centralization=1.0).cpu().numpy()
+    assert np.isfinite(got).all()
+    rel = rotate_rel_error(oracle, a, b, got, want, 1.0)
+    print(f"rotate {shape} x {scale:g}: relative error {rel:.3e}")
+    assert rel <= 1e-3, (shape, scale, rel)
+
+
 def test_full_config4_job_properties_and_sampled_keys(oracle):
     """BASELINE config 4 at FULL size: rotate(A, B, alignment=1, alpha=0) over every key of two SDXL-shaped bf16 checkpoints
     through merge() (files on tmpfs -> batched plan -> one fp32 file), checked where no CPU SVD of the whole job is affordable:
