@@ -1481,7 +1481,8 @@ int rotate_run(const RotCall &c) {
     const char *prec_env = getenv("MECHA_ROT_PREC");
     const bool plain = vec8 && c.alignment == 1 && c.alpha == 0.0f && c.transform_in == nullptr && (n & 7) == 0 && (p & 7) == 0 &&
                        !(prec_env != nullptr && strcmp(prec_env, "f32") == 0);
-    const bool tall_h = plain && n >= p && p >= 256, wide_h = plain && n < p && n >= 256;
+    // (wide keys: the images of P = Bc Qb and D = x (Z - Qb^T)^T hold entries up to 2 sqrt(p) and 4 sqrt(p): within fp16's range / 64 up to p = 65536)
+    const bool tall_h = plain && n >= p && p >= 256, wide_h = plain && n < p && n >= 256 && p <= 65536;
     _Float16 *ac_img = reinterpret_cast<_Float16 *>(ac), *bx_img = reinterpret_cast<_Float16 *>(bc), *act_img = reinterpret_cast<_Float16 *>(y);
     const dim3 tile_grid((unsigned)((p + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)count);
     if (tall_h)             // bx_img: Bc^T
