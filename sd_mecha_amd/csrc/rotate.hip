@@ -566,6 +566,85 @@ __device__ __forceinline__ void gemm128h_finish(f32x16 (&acc)[2][2], float *c, c
     if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
 }
 
+// The same epilogue staged through LDS (the k-loop's buffers are free by then), so that every global access is 16 bytes of one
+// row: written straight from the accumulator layout (a lane = one column) the images took two 2-byte stores and the axpy term
+// two 2-byte loads per ELEMENT -- as many memory instructions as the whole k-loop issued.  Two halves of 64 rows (33 KiB each):
+// the two waves that own the half store their accumulators as fp32 [row][132]; then every thread takes groups of 8 consecutive
+// columns of a row (axpy term: one 32-byte slot of the image; results: `out` / C / `sp` in whole 16-byte pieces) and writes the
+// finished values back; then, for what goes out transposed (mirror tile, `spt`), groups of 8 consecutive rows of a column.
+// M % 8 == 0 and N % 8 == 0 (images), so a group is inside the matrix or outside it as a whole.
+constexpr int HF_PITCH = 132;
+__device__ __forceinline__ void gemm128h_finish_lds(f32x16 (&acc)[2][2], float *tile /* 64 x HF_PITCH floats of LDS */, float *c, const GemmEpilogue &ee,
+                                                    int64_t M, int64_t N, int64_t bm0, int64_t bn0, int wm, int wn, int i, int kk, bool symmetric, bool mirror) {
+    _Float16 *tsp = symmetric ? (mirror ? ee.sp : nullptr) : ee.spt;
+    float *tc = (symmetric && mirror) ? c : nullptr;
+    const float scale = ee.acc_scale != nullptr ? *ee.acc_scale : 1.0f;
+    const int tid = threadIdx.x;
+    bool bad = false;
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();                                        // the k-loop's last LDS reads / the previous half's transposed reads are done
+        if (wm == 64 * half) {
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        tile[(32 * tm + (r & 3) + 8 * (r >> 2) + 4 * kk) * HF_PITCH + wn + 32 * tn + i] = acc[tm][tn][r];
+        }
+        __syncthreads();
+        const int64_t row_base = bm0 + 64 * half;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                           // 64 rows x 16 column groups = 1024 groups of 8
+            const int gidx = tid + 256 * j, lr = gidx >> 4, lc = (gidx & 15) * 8;
+            const int64_t row = row_base + lr, col = bn0 + lc;
+            if (row >= M || col >= N) continue;
+            float *tp = tile + lr * HF_PITCH + lc;
+            f32x4 v0 = *reinterpret_cast<const f32x4 *>(tp), v1 = *reinterpret_cast<const f32x4 *>(tp + 4);
+            const int64_t at = split_at(row, col, N);
+            if (ee.axpy_img != nullptr) {
+                const f16x8 xh = *reinterpret_cast<const f16x8 *>(ee.axpy_img + at), xl = *reinterpret_cast<const f16x8 *>(ee.axpy_img + at + 8);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v0[q] = __builtin_fmaf(ee.axpy_a, ((float)xh[q] + (float)xl[q]) * (1.0f / H_SCALE), ee.axpy_b * v0[q]);
+                    v1[q] = __builtin_fmaf(ee.axpy_a, ((float)xh[q + 4] + (float)xl[q + 4]) * (1.0f / H_SCALE), ee.axpy_b * v1[q]);
+                }
+            }
+            f32x4 b0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
+            if (ee.col_bias != nullptr) { b0 = *reinterpret_cast<const f32x4 *>(ee.col_bias + col); b1 = *reinterpret_cast<const f32x4 *>(ee.col_bias + col + 4); }
+            v0 = v0 * scale + b0; v1 = v1 * scale + b1;
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (ee.out != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) bad |= nonfinite_f32(v[q]);
+                const int64_t idx = ee.out_off + row * N + col;
+                const bool vec = (idx & 7) == 0 && (reinterpret_cast<uintptr_t>(ee.out) & 15u) == 0;   // (arena offsets are multiples of 128 elements; a lone key's pointer may not be aligned)
+                if (ee.out_dt == MECHA_BF16) { if (vec) store8<MECHA_BF16, true>(ee.out, idx, v); else for (int q = 0; q < 8; q++) store1<MECHA_BF16>(ee.out, idx + q, v[q]); }
+                else if (ee.out_dt == MECHA_F16) { if (vec) store8<MECHA_F16, true>(ee.out, idx, v); else for (int q = 0; q < 8; q++) store1<MECHA_F16>(ee.out, idx + q, v[q]); }
+                else { if (vec) store8<MECHA_F32, true>(ee.out, idx, v); else for (int q = 0; q < 8; q++) store1<MECHA_F32>(ee.out, idx + q, v[q]); }
+            } else if (c != nullptr) {
+                *reinterpret_cast<f32x4 *>(c + row * N + col) = v0; *reinterpret_cast<f32x4 *>(c + row * N + col + 4) = v1;
+            }
+            if (ee.sp != nullptr) { split_store4(ee.sp, at, v0); split_store4(ee.sp, at + 4, v1); }
+            if (tsp != nullptr || tc != nullptr) { *reinterpret_cast<f32x4 *>(tp) = v0; *reinterpret_cast<f32x4 *>(tp + 4) = v1; }
+        }
+        if (tsp == nullptr && tc == nullptr) continue;          // (block-uniform)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                           // 128 columns x 8 row groups of 8
+            const int gidx = tid + 256 * j, lc = gidx & 127, lr = (gidx >> 7) * 8;
+            const int64_t row = row_base + lr, col = bn0 + lc;
+            if (row >= M || col >= N) continue;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { v0[q] = tile[(lr + q) * HF_PITCH + lc]; v1[q] = tile[(lr + 4 + q) * HF_PITCH + lc]; }
+            if (tsp != nullptr) { const int64_t at = split_at(col, row, M); split_store4(tsp, at, v0); split_store4(tsp, at + 4, v1); }
+            if (tc != nullptr) { *reinterpret_cast<f32x4 *>(tc + col * M + row) = v0; *reinterpret_cast<f32x4 *>(tc + col * M + row + 4) = v1; }
+        }
+    }
+    if (bad && ee.flags != nullptr) atomicOr(ee.flags, MECHA_FLAG_OUTPUT_NONFINITE);
+}
+
 // symmetric: A and B are the same operand (C = X X^T, or G G of a symmetric G) and the epilogue is at most the axpy of a
 // symmetric matrix.  Only the tiles on and above the diagonal are computed; a tile above it is also stored transposed
 // (every lane holds 4 consecutive rows of one column = 16 contiguous bytes of the transposed tile).  The result is symmetric
@@ -766,7 +845,8 @@ __global__ __launch_bounds__(256, (HK == 16 && D == 1) ? 3 : 2) void gemm128h_ke
     float *c = (C == nullptr) ? nullptr : C + (int64_t)slab * M * N;
     GemmEpilogue ee = epilogue_for_key(e, bt, key);
     if (n_slabs > 1) ee = GemmEpilogue{};
-    gemm128h_finish(acc, c, ee, M, N, bm0, bn0, wm, wn, i, kk, symmetric != 0, bx > by);
+    if constexpr (HK == 32) gemm128h_finish_lds(acc, reinterpret_cast<float *>(&lds[0][0][0]), c, ee, M, N, bm0, bn0, wm, wn, i, kk, symmetric != 0, bx > by);
+    else gemm128h_finish(acc, c, ee, M, N, bm0, bn0, wm, wn, i, kk, symmetric != 0, bx > by);
 }
 
 // The factor a key's matrix is multiplied by on its way into an image (rot_split_kernel), from the key's scalars:
