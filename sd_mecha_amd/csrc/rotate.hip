@@ -864,23 +864,38 @@ __device__ __forceinline__ float split_factor(int mode, const double *scal) {
 // sp = the split image of f x (x: r x c row-major fp32, f: split_factor), spt (nullable) = the image of its transpose; every key of
 // the batch that `skip` does not excuse.  64 x 64 tiles through LDS.  r % 8 == 0 and c % 8 == 0.
 __global__ __launch_bounds__(256) void rot_split_kernel(const float *x, _Float16 *sp, _Float16 *spt, int64_t r, int64_t c, int mode, const double *scal, Batch bt) {
-    __shared__ float tile[64][65];
+    __shared__ __attribute__((aligned(16))) float tile[64][68];
     const int key = blockIdx.z;
     if (bt.skip != nullptr && bt.skip[key] != 0u) return;
     x = key_ptr(x, bt, key); sp = key_ptr(sp, bt, key); spt = key_ptr(spt, bt, key);
     const float f = split_factor(mode, key_ptr(scal, bt, key));
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int j = ty; j < 64; j += 4)
-        if (r0 + j < r && c0 + tx < c) {
-            const float v = x[(r0 + j) * c + c0 + tx] * f;
-            tile[j][tx] = v;
-            split_store1(sp, split_at(r0 + j, c0 + tx, c), v);
+    // groups of 8 consecutive values of a row (whole slots: 32 contiguous bytes of the image), two per thread
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int gidx = threadIdx.x + 256 * j, lr = gidx >> 3, lc = (gidx & 7) * 8;
+        if (r0 + lr < r && c0 + lc < c) {
+            const float *src = x + (r0 + lr) * c + c0 + lc;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src) * f, v1 = *reinterpret_cast<const f32x4 *>(src + 4) * f;
+            const int64_t at = split_at(r0 + lr, c0 + lc, c);
+            split_store4(sp, at, v0); split_store4(sp, at + 4, v1);
+            *reinterpret_cast<f32x4 *>(&tile[lr][lc]) = v0; *reinterpret_cast<f32x4 *>(&tile[lr][lc + 4]) = v1;
         }
+    }
     if (spt == nullptr) return;
     __syncthreads();
-    for (int j = ty; j < 64; j += 4)
-        if (c0 + j < c && r0 + tx < r) split_store1(spt, split_at(c0 + j, r0 + tx, r), tile[tx][j]);
+    // the transpose: groups of 8 consecutive ROWS of one column
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int gidx = threadIdx.x + 256 * j, lc = gidx & 63, lr = (gidx >> 6) * 8;
+        if (r0 + lr < r && c0 + lc < c) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { v0[q] = tile[lr + q][lc]; v1[q] = tile[lr + 4 + q][lc]; }
+            const int64_t at = split_at(c0 + lc, r0 + lr, r);
+            split_store4(spt, at, v0); split_store4(spt, at + 4, v1);
+        }
+    }
 }
 // scal[2] += sum x^2 (fp64; zeroed by the host)
 __global__ __launch_bounds__(256) void rot_sumsq_kernel(const float *x, int64_t n, double *scal, Batch bt) {
@@ -933,7 +948,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *slabs, in
 __global__ __launch_bounds__(256) void rot_center_img_kernel(const void *a, const void *b, int dt, int64_t n, int64_t p, const float *a_mean,
                                                              const float *b_mean, _Float16 *ac_img, _Float16 *act_img, _Float16 *bct_img, _Float16 *bc_img,
                                                              float *bc_f32, const double *scal, Batch bt) {
-    __shared__ float ta[64][65], tb[64][65];
+    __shared__ __attribute__((aligned(16))) float ta[64][68], tb[64][68];
     const int key = blockIdx.z;
     const int64_t base = key_off(bt, key);
     const float *ts = reinterpret_cast<const float *>(key_ptr(scal, bt, key) + ROT_SCAL_T);
@@ -942,24 +957,43 @@ __global__ __launch_bounds__(256) void rot_center_img_kernel(const void *a, cons
     ac_img = key_ptr(ac_img, bt, key); act_img = key_ptr(act_img, bt, key); bct_img = key_ptr(bct_img, bt, key); bc_img = key_ptr(bc_img, bt, key);
     bc_f32 = key_ptr(bc_f32, bt, key);
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const float am = c0 + tx < p ? a_mean[c0 + tx] : 0.0f, bm = c0 + tx < p ? b_mean[c0 + tx] : 0.0f;
-    for (int j = ty; j < 64; j += 4)
-        if (r0 + j < n && c0 + tx < p) {
-            const int64_t at = (r0 + j) * p + c0 + tx;
-            const float x = (ld_any(dt, a, base + at) - am) * sa, y = (ld_any(dt, b, base + at) - bm) * sb;   // (svd.py:69-70), times t_a / t_b
-            ta[j][tx] = x; tb[j][tx] = y;
-            split_store1(ac_img, split_at(r0 + j, c0 + tx, p), x);
-            if (bc_img != nullptr) split_store1(bc_img, split_at(r0 + j, c0 + tx, p), y);
-            if (bc_f32 != nullptr) bc_f32[at] = y;
+    // groups of 8 consecutive values of a row (16-byte loads of 16-bit inputs: the caller checked the alignment), two per thread
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int gidx = threadIdx.x + 256 * j, lr = gidx >> 3, lc = (gidx & 7) * 8;
+        if (r0 + lr < n && c0 + lc < p) {
+            const int64_t at = (r0 + lr) * p + c0 + lc;
+            float x[8], y[8];
+            if (dt == MECHA_BF16) { load8<MECHA_BF16>(a, base + at, x); load8<MECHA_BF16>(b, base + at, y); }
+            else if (dt == MECHA_F16) { load8<MECHA_F16>(a, base + at, x); load8<MECHA_F16>(b, base + at, y); }
+            else { load8<MECHA_F32>(a, base + at, x); load8<MECHA_F32>(b, base + at, y); }
+            f32x4 x0, x1, y0, y1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                       // (svd.py:69-70), times t_a / t_b
+                x0[q] = (x[q] - a_mean[c0 + lc + q]) * sa; x1[q] = (x[q + 4] - a_mean[c0 + lc + 4 + q]) * sa;
+                y0[q] = (y[q] - b_mean[c0 + lc + q]) * sb; y1[q] = (y[q + 4] - b_mean[c0 + lc + 4 + q]) * sb;
+            }
+            const int64_t im = split_at(r0 + lr, c0 + lc, p);
+            split_store4(ac_img, im, x0); split_store4(ac_img, im + 4, x1);
+            if (bc_img != nullptr) { split_store4(bc_img, im, y0); split_store4(bc_img, im + 4, y1); }
+            if (bc_f32 != nullptr) { *reinterpret_cast<f32x4 *>(bc_f32 + at) = y0; *reinterpret_cast<f32x4 *>(bc_f32 + at + 4) = y1; }
+            *reinterpret_cast<f32x4 *>(&ta[lr][lc]) = x0; *reinterpret_cast<f32x4 *>(&ta[lr][lc + 4]) = x1;
+            *reinterpret_cast<f32x4 *>(&tb[lr][lc]) = y0; *reinterpret_cast<f32x4 *>(&tb[lr][lc + 4]) = y1;
         }
+    }
     __syncthreads();
-    for (int j = ty; j < 64; j += 4)
-        if (c0 + j < p && r0 + tx < n) {
-            const int64_t at = split_at(c0 + j, r0 + tx, n);
-            split_store1(act_img, at, ta[tx][j]);
-            if (bct_img != nullptr) split_store1(bct_img, at, tb[tx][j]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                               // the transposes: 8 consecutive rows of one column
+        const int gidx = threadIdx.x + 256 * j, lc = gidx & 63, lr = (gidx >> 6) * 8;
+        if (r0 + lr < n && c0 + lc < p) {
+            f32x4 x0, x1, y0, y1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { x0[q] = ta[lr + q][lc]; x1[q] = ta[lr + 4 + q][lc]; y0[q] = tb[lr + q][lc]; y1[q] = tb[lr + 4 + q][lc]; }
+            const int64_t at = split_at(c0 + lc, r0 + lr, n);
+            split_store4(act_img, at, x0); split_store4(act_img, at + 4, x1);
+            if (bct_img != nullptr) { split_store4(bct_img, at, y0); split_store4(bct_img, at + 4, y1); }
         }
+    }
 }
 // img = the image of x - y (both n x p fp32), every key of the batch
 __global__ __launch_bounds__(256) void rot_diff_img_kernel(const float *x, const float *y, _Float16 *img, int64_t n, int64_t p, Batch bt) {
@@ -1328,8 +1362,14 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
     int ib = 0;                                                 // img->x[ib], img->xt[ib]: the images of cur and cur^T ...
     bool t_valid = false;                                       // ... when this says so
     const int count = g.bt.count;
+    // when: every POLAR_DEFLATE_EVERY steps and at the end; in a schedule of <= 8 steps at the end only (the direction starts at
+    // rounding level, ~1e-8, and grows at most 5.6 x 3.86^5 = 4 800-fold over the short schedule's 6 steps: still 5e-5 when the
+    // closing deflation removes it -- and every deflation costs an fp32 round trip of the iterate and new images)
+    auto deflates_after = [&](int it, int n_steps) {
+        return deflate_ones && (it + 1 == n_steps || (n_steps > 8 && (it + 1) % POLAR_DEFLATE_EVERY == 0));
+    };
     auto deflate = [&](int it, int n_steps) {
-        if (deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == n_steps)) {
+        if (deflates_after(it, n_steps)) {
             MECHA_LAUNCH(MK_ROT_NORMS, rot_deflate_ones_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)count), dim3(256), 0, g.s, cur, r, c, g.bt);
             t_valid = false;
         }
@@ -1359,7 +1399,7 @@ int polar_newton_schulz(float *X, float *tmp, float *G, float *G2, int64_t r, in
             } else if (!t_valid)
                 MECHA_LAUNCH(MK_ROT_NORMS, rot_split_kernel, sgrid, dim3(256), 0, g.s, cur, img->x[ib], img->xt[ib], r, c, (int)SPLIT_PLAIN, scal, g.bt);
             // images for the next step unless it is an fp32 step or the deflation (which works on the fp32 iterate) comes first
-            const bool deflates = deflate_ones && ((it + 1) % POLAR_DEFLATE_EVERY == 0 || it + 1 == n_steps);
+            const bool deflates = deflates_after(it, n_steps);
             const bool next_split = it + 1 < n_steps - f32_tail && !deflates;
             // (the fp32 iterate is written by the last step of such a run only; in between, `nxt` is a stale buffer)
             polar_step_h(next_split ? nullptr : nxt, r, c, st, g, img->x[ib], img->xt[ib], img->g, img->g2, next_split ? img->x[ib ^ 1] : nullptr,
