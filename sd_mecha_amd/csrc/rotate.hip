@@ -1127,7 +1127,10 @@ void gemm_h(const _Float16 *a, const _Float16 *b, float *C, int64_t M, int64_t N
     const int sym = (symmetric && z == 1 && M == N && e.spt == nullptr && e.out == nullptr && e.col_bias == nullptr) ? 1 : 0;
     const HOperand A{a, 2 * K}, B{b, 2 * K};
 #define MECHA_GEMMH(HK_, D_) MECHA_LAUNCH(MK_ROT_GEMM, (gemm128h_kernel<HK_, D_>), grid, block, 0, g.s, A, B, dst, M, N, K, k_per, (int)z, g.bt, z == 1 ? e : none, sym)
-    if (hk == 32) MECHA_GEMMH(32, 2);
+    static const int hd = [] { const char *v = getenv("MECHA_ROT_HD"); return v != nullptr ? atoi(v) : 2; }();
+    if (hk == 32 && hd == 1) MECHA_GEMMH(32, 1);
+    else if (hk == 32 && hd == 3) MECHA_GEMMH(32, 3);
+    else if (hk == 32) MECHA_GEMMH(32, 2);
     else MECHA_GEMMH(16, 1);
 #undef MECHA_GEMMH
     if (z > 1) {
