@@ -835,7 +835,10 @@ def merge(
     models = collect_models(recipe)
     if not models:
         raise ValueError("the recipe has no model inputs")
-    readers = {id(m): open_reader(m.path) for m in models}
+    last_stats.clear()
+    with _phase("open_inputs"):
+        readers = {id(m): open_reader(m.path) for m in models}
+    t_plan = time.perf_counter()
     try:
         plan = fuse(recipe)
         if plan is not None and plan.kind == "rotate" and cache and any(n is plan.node for n in cache):
@@ -878,8 +881,10 @@ def merge(
         order = {k: i for i, (k, _) in enumerate(items)}
         my_items.sort(key=lambda kv: order[kv[0]])
 
+        last_stats["plan"] = time.perf_counter() - t_plan       # fuse, config inference, key analysis, recipe text
         to_file = isinstance(output, (str, pathlib.Path))
         sink: Any
+        t_sink = time.perf_counter()
         if to_file:
             out_path = pathlib.Path(output)
             esz = DTYPE_REVERSE_MAPPING[output_dtype][1]
@@ -904,9 +909,10 @@ def merge(
         # (a checkpoint may keep, say, its VAE in fp32 beside a bf16 UNet); everything else -- integer keys (position_ids: the
         # reference casts them to fp32 like any other key, merging.py:673-681), keys whose inputs disagree on the dtype, empty
         # tensors, keys one of the fused inputs lacks -- is evaluated per key into the same sink.
+        last_stats["open_output"] = time.perf_counter() - t_sink
         skipped: List[str] = []
-        last_stats.clear()
-        groups, generic_items = _split_fusable(plan, readers, my_items, header)
+        with _phase("split_fusable"):
+            groups, generic_items = _split_fusable(plan, readers, my_items, header)
         for in_dtype, group_items in groups.items():
             _run_fused(plan, backend, readers, group_items, in_dtype, header, sink, to_file, output_device, output_dtype,
                        total_buffer_size, check_finite_output, skipped)
@@ -939,7 +945,8 @@ def merge(
                     sink.close(write_header=False)
                 dist.barrier()
             else:
-                sink.close()
+                with _phase("close_output"):
+                    sink.close()
                 if skipped:
                     compact_holes(out_path)
             return None
