@@ -430,6 +430,17 @@ int mecha_host_mmap_write_many(int fd, const void *const *src, const size_t *nby
  * in pinned host memory (the reference has no counterpart: its cast node copies from pageable memory, logistics.py:53). */
 int mecha_host_h2d_many(void *const *dst_dev, const void *const *src_host, const size_t *nbytes, int64_t n, void *stream);
 
+/* The JSON header of a .safetensors file as flat tables (replaces the json.loads of reference sd_mecha/streaming.py:141-149 on the
+ * read side: 10-17 ms of interpreter time per LoRA file, 17 files per LoRA job).  json / len: the header text after the 8-byte
+ * length.  Tensors come out ordered by data offset (as the reference orders them): the names NUL-terminated one after the other in
+ * `names` (room for `len` bytes, *names_bytes = bytes used), dtype_code[i] = index into {F64, I64, F32, I32, F16, BF16, I16, I8,
+ * U8, BOOL}, ndim[i] (<= 8), shape[8 i ..], offsets[2 i], [2 i + 1] = data_offsets.  metadata_span[0], [1] = offset and length of
+ * the "__metadata__" value (0, 0 when absent).  Returns the number of tensors, or -1 for a header it does not read (another dtype
+ * tag, more than 8 dimensions, more than max_entries tensors, a name with a JSON escape, malformed text): fall back to a JSON
+ * reader then.  No GPU needed. */
+int64_t mecha_host_parse_safetensors_header(const char *json, int64_t len, int64_t max_entries, char *names, int64_t *names_bytes,
+                                            int32_t *dtype_code, int32_t *ndim, int64_t *shape, int64_t *offsets, int64_t *metadata_span);
+
 #ifdef __cplusplus
 }
 #endif

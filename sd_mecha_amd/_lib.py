@@ -68,6 +68,7 @@ SIGNATURES = {
     "mecha_host_pread_many": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i]),
     "mecha_host_pwrite_many": (c_i, [c_i, c_p, c_p, c_p, c_i64, c_i]),
     "mecha_host_h2d_many": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
+    "mecha_host_parse_safetensors_header": (c_i64, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mecha_host_mmap_write_many": (c_i, [c_i, c_p, c_p, c_p, c_i64, c_i]),
     "mecha_ties_select_stats": (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_p]),
     "mecha_ties_sum": (c_i, [c_p, c_i, c_p, c_i64, c_i, c_i, c_d, c_i, c_p, c_p, c_sz, c_p, c_p]),

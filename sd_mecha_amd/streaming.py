@@ -17,6 +17,7 @@ are rejected (reference :87-88).
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import mmap
 import os
@@ -87,6 +88,80 @@ def read_header(path: pathlib.Path) -> Tuple[int, Dict[str, dict]]:
     return header_size, ordered
 
 
+_DTYPE_BY_CODE = (torch.float64, torch.int64, torch.float32, torch.int32, torch.float16, torch.bfloat16, torch.int16, torch.int8,
+                  torch.uint8, torch.bool)          # the tag order of mecha_host_parse_safetensors_header
+
+
+def read_header_tables(path: pathlib.Path):
+    """(header_size, {name: TensorMetadata} in data-offset order, the file's ``__metadata__`` dict) through the library's header
+    scanner (csrc/hostio.cpp: a LoRA job opens 17 files with 60 000 entries between them -- 0.25 s of ``json.loads`` and dict
+    building in one interpreter thread, 0.04 s this way); None when the library is not built or does not read this header
+    (an exotic dtype tag, > 8 dimensions): the caller then takes the JSON path."""
+    try:
+        from . import _lib
+        L = _lib.lib()
+    except Exception:
+        return None
+    with open(path, "rb") as f:
+        size_bytes = f.read(8)
+        if len(size_bytes) != 8:
+            raise ValueError(f"{path}: not a safetensors file (too short)")
+        (header_size,) = struct.unpack("<Q", size_bytes)
+        text = f.read(header_size)
+    cap = len(text) // 48 + 8                                   # an entry takes more than 48 bytes of text
+    names_buf = ctypes.create_string_buffer(max(len(text), 1))
+    used = ctypes.c_int64(0)
+    codes, ndim = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
+    shapes, offsets, meta_span = np.empty((cap, 8), dtype=np.int64), np.empty((cap, 2), dtype=np.int64), np.zeros(2, dtype=np.int64)
+    n = L.mecha_host_parse_safetensors_header(text, len(text), cap, names_buf, ctypes.byref(used), codes.ctypes.data, ndim.ctypes.data,
+                                              shapes.ctypes.data, offsets.ctypes.data, meta_span.ctypes.data)
+    if n < 0:
+        return None
+    names = names_buf.raw[:used.value - 1].decode("utf-8").split("\0") if n else []     # already in data-offset order (reference :141-149)
+    file_meta = json.loads(text[meta_span[0]:meta_span[0] + meta_span[1]]) if meta_span[1] else {}
+    return header_size, _HeaderTable(names, codes[:n], ndim[:n], shapes[:n], offsets[:n]), (file_meta if isinstance(file_meta, dict) else {})
+
+
+class _HeaderTable(Mapping):
+    """{name: TensorMetadata} over the scanner's tables, in data-offset order; an entry becomes Python objects when somebody asks for
+    it (membership tests and key listings never do: the 16 LoRA files of a LoRA job are only asked "do you hold <prefix>.lora_up.weight"
+    until the loader thread reads them)."""
+
+    def __init__(self, names, codes, ndim, shapes, offsets):
+        self._index = dict(zip(names, range(len(names))))
+        self._codes, self._ndim, self._shapes, self._offsets = codes, ndim, shapes, offsets
+        self._made: Dict[str, TensorMetadata] = {}
+
+    def __contains__(self, key):
+        return key in self._index
+
+    def __len__(self):
+        return len(self._index)
+
+    def __iter__(self):
+        return iter(self._index)
+
+    def keys(self):
+        return self._index.keys()
+
+    def __getitem__(self, key):
+        m = self._made.get(key)
+        if m is None:
+            i = self._index[key]
+            start, end = self._offsets[i].tolist()
+            m = self._made[key] = TensorMetadata.from_header(self._shapes[i, :self._ndim[i]].tolist(), _DTYPE_BY_CODE[self._codes[i]], start, end)
+        return m
+
+    def items(self):
+        if len(self._made) < len(self._index):                  # everything at once: one conversion per table
+            nd, sh, of, cd = self._ndim.tolist(), self._shapes.tolist(), self._offsets.tolist(), self._codes.tolist()
+            from_header, made = TensorMetadata.from_header, self._made
+            for k, i in self._index.items():
+                if k not in made:
+                    made[k] = from_header(sh[i][:nd[i]], _DTYPE_BY_CODE[cd[i]], of[i][0], of[i][1])
+        return ((k, self._made[k]) for k in self._index)
+
+
 class InSafetensorsDict(Mapping):
     """Read side (protocol of reference :59-82: keys / metadata / __getitem__ / close)."""
 
@@ -95,17 +170,20 @@ class InSafetensorsDict(Mapping):
         if file_path.suffix != ".safetensors":
             raise ValueError(f"Model type not supported: {file_path} (only safetensors are supported)")
         self.file_path = file_path
-        self.header_size, self.header = read_header(file_path)
+        tables = read_header_tables(file_path)
+        if tables is not None:
+            self.header_size, self._meta, self._file_metadata = tables
+        else:
+            self.header_size, header = read_header(file_path)
+            from_header, dtypes = TensorMetadata.from_header, DTYPE_MAPPING
+            self._meta = {k: from_header(v["shape"], dtypes[v["dtype"]][0], *v["data_offsets"]) for k, v in header.items() if k != "__metadata__"}
+            self._file_metadata = dict(header.get("__metadata__", {}) or {})
+        self._meta_as_stored = self._meta                       # apply_aliases replaces _meta, never mutates it
         self.data_start = 8 + self.header_size
         self._file = open(file_path, "rb")
         size = os.fstat(self._file.fileno()).st_size
         self._mmap = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ) if size > 0 else None
         self._view = memoryview(self._mmap) if self._mmap is not None else memoryview(b"")
-        from_header, dtypes = TensorMetadata.from_header, DTYPE_MAPPING
-        self._meta = {
-            k: from_header(v["shape"], dtypes[v["dtype"]][0], *v["data_offsets"])
-            for k, v in self.header.items() if k != "__metadata__"
-        }
 
     def apply_aliases(self, resolve) -> None:
         """Re-key the tensors by their canonical names (``resolve``: alias -> key of the model config, identity for
@@ -135,7 +213,7 @@ class InSafetensorsDict(Mapping):
         return self._meta.items()
 
     def file_metadata(self) -> dict:
-        return dict(self.header.get("__metadata__", {}) or {})
+        return dict(self._file_metadata)
 
     def meta(self, key: str) -> TensorMetadata:
         try:
@@ -234,8 +312,7 @@ def open_reader(path) -> InSafetensorsDict:
     """The reader merge() uses for an input: the preloaded pinned image if there is one, else an mmap of the file."""
     hit = _PRELOADED.get(str(pathlib.Path(path).resolve()))
     if hit is not None:
-        hit._meta = {k: TensorMetadata.from_header(v["shape"], DTYPE_MAPPING[v["dtype"]][0], *v["data_offsets"])
-                     for k, v in hit.header.items() if k != "__metadata__"}        # undo a previous merge's alias renaming
+        hit._meta = hit._meta_as_stored                         # undo a previous merge's alias renaming
         return hit
     return InSafetensorsDict(path)
 

@@ -127,3 +127,61 @@ assert np.array_equal(got, want)
 """
     env = dict(os.environ, MECHA_HOST_NT="1", PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=120)
+
+
+def test_native_safetensors_header_matches_the_json_reader(tmp_path):
+    """mecha_host_parse_safetensors_header (the read side's replacement for json.loads, reference streaming.py:141-149): the same
+    keys in the same (data offset) order with the same shapes, dtypes and offsets as the JSON path, non-ASCII names and a
+    ``__metadata__`` value full of braces and quotes included; a header it does not read (a name with a JSON escape, 9 dimensions,
+    an unknown dtype tag, malformed text) falls back to the JSON path."""
+    import json
+    import struct
+    import torch
+    import safetensors.torch
+    from sd_mecha_amd import streaming
+    tensors = {
+        "plain.weight": torch.zeros(3, 5, dtype=torch.float16), "scalar": torch.tensor(2.0), "empty": torch.zeros(0, 4, dtype=torch.bfloat16),
+        "unicode é中": torch.zeros(2, 2, 2, dtype=torch.int64),
+        "bool": torch.zeros(7, dtype=torch.bool), "u8": torch.zeros(9, dtype=torch.uint8), "i32": torch.zeros(1, 1, 1, 1, dtype=torch.int32),
+    }
+    tensors.update({f"lora_unet_{i}.lora_up.weight": torch.zeros(4, 2, dtype=torch.float16) for i in range(300)})
+    path = tmp_path / "h.safetensors"
+    safetensors.torch.save_file(tensors, str(path), metadata={"mecha_recipe": 'merge "x" {"a": [1, 2]} \\ }{', "format": "pt"})
+    tables = streaming.read_header_tables(path)
+    assert tables is not None
+    size, meta, file_meta = tables
+    size_json, header = streaming.read_header(path)
+    assert size == size_json
+    want = [(k, v) for k, v in header.items() if k != "__metadata__"]
+    assert list(meta) == [k for k, _ in want]
+    for k, v in want:
+        m = meta[k]
+        assert m.shape == tuple(v["shape"]) and m.dtype == streaming.DTYPE_MAPPING[v["dtype"]][0] and [m.start, m.end] == v["data_offsets"], k
+    assert file_meta == header["__metadata__"]
+    reader = streaming.InSafetensorsDict(path)
+    assert set(reader.keys()) == set(tensors) and reader.file_metadata()["format"] == "pt"
+    assert torch.equal(reader["plain.weight"], tensors["plain.weight"]) and reader["unicode é中"].shape == (2, 2, 2)
+    assert "lora_unet_7.lora_up.weight" in reader and "lora_unet_7.lora_down.weight" not in reader and len(reader) == len(tensors)
+    reader.close()
+    esc = {'quote"and\\backslash': torch.zeros(2, dtype=torch.float32), "b": torch.ones(3)}
+    p1 = tmp_path / "esc.safetensors"
+    safetensors.torch.save_file(esc, str(p1))
+    assert streaming.read_header_tables(p1) is None
+    r1 = streaming.InSafetensorsDict(p1)
+    assert r1['quote"and\\backslash'].shape == (2,) and torch.equal(r1["b"], esc["b"])
+    r1.close()
+    # a header the scanner does not read (9 dimensions; a dtype tag it does not know): None, and the reader still opens the file
+    odd = {"nine": {"dtype": "F32", "shape": [1] * 9, "data_offsets": [0, 4]}}
+    text = json.dumps(odd).encode()
+    p2 = tmp_path / "odd.safetensors"
+    p2.write_bytes(struct.pack("<Q", len(text)) + text + b"\0" * 4)
+    assert streaming.read_header_tables(p2) is None
+    assert streaming.InSafetensorsDict(p2).meta("nine").shape == (1,) * 9
+    text = json.dumps({"x": {"dtype": "F8_E4M3", "shape": [4], "data_offsets": [0, 4]}}).encode()
+    p3 = tmp_path / "f8.safetensors"
+    p3.write_bytes(struct.pack("<Q", len(text)) + text + b"\0" * 4)
+    assert streaming.read_header_tables(p3) is None
+    for bad in (b"", b"{", b'{"a": {"dtype": "F32", "shape": [1], "data_offsets": [0]}}', b'{"a": 3}', b'{"a": {"dtype": "F32", "shape": [1], "data_offsets": [0, 4]}} x'):
+        p4 = tmp_path / "bad.safetensors"
+        p4.write_bytes(struct.pack("<Q", len(bad)) + bad)
+        assert streaming.read_header_tables(p4) is None
