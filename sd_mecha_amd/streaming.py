@@ -128,6 +128,7 @@ class _HeaderTable(Mapping):
     until the loader thread reads them)."""
 
     def __init__(self, names, codes, ndim, shapes, offsets):
+        self.names = names
         self._index = dict(zip(names, range(len(names))))
         self._codes, self._ndim, self._shapes, self._offsets = codes, ndim, shapes, offsets
         self._made: Dict[str, TensorMetadata] = {}
