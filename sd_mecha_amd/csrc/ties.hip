@@ -224,60 +224,94 @@ __device__ __forceinline__ uint32_t bracket_bin(uint32_t t, uint32_t shift, uint
     return ((t + low_mask) >> shift) + (t >> shift);              // ceil(t / 2^shift) + floor(t / 2^shift) = 2q + (remainder != 0)
 }
 
-// Three 16-bit deltas (the SDXL x4 job; the second group of a FLUX x8 stripe) fit 5 waves per SIMD (95 VGPRs; the CAP = 4
-// instantiation needs 115 and spills 168 when forced): count pass 5.11 -> 4.97 ms (SDXL), 2 x 2.4 -> 4.6 ms (FLUX stripe).
-template <int CAP, bool W32>
+// LDS layout of the count pass, per delta: COUNT_LOW words that count the elements below the bracket (per-lane words, summed at
+// the flush), the TIES_BINS bins of the bracket, COUNT_HIGH write-only words for the elements above it.
+constexpr int COUNT_LOW = 66, COUNT_HIGH = 66;
+constexpr int COUNT_STRIDE = COUNT_LOW + TIES_BINS + COUNT_HIGH;
+static_assert(COUNT_STRIDE % 2 == 0, "the count kernel folds word offsets into the bias as pairs of words");
+
+// Clamped binning.  92 % of the elements lie outside the bracket, and a wave nearly always holds some that lie inside, so the
+// pass is branch-free per element; what it costs is VALU issue (as long as the memory time).  Instead of testing
+// "inside?" and selecting a dump word (compare, select, sign extraction and a per-lane below counter: 10.5 instructions per
+// element and delta), the pattern is CLAMPED into [low_clamp, high_clamp] -- per-lane patterns a few cells outside the bracket,
+// chosen so that every lane's clamp values fall into LDS words of their own -- and binned like any other: |x|, clamp, two shifted
+// copies and an add-shift, 6-7 instructions.  The words the low clamps hit are real counters (the "below" count), those of the high
+// clamps are never read.  Needs room for 33 cells of patterns on either side of the bracket and a bracket that ends on a cell
+// boundary (ties_sample_kernel sees to it); brackets at the ends of the pattern range take the compare-and-select form.
+//   t = pattern - (lo - 33 cells);  word = floor(t / cell) + ceil(t / cell)   (bracket_bin(), shifted by COUNT_LOW = 66 words)
+//   (in the kernel t also carries the LDS address of the delta's words, as address / 8 cells: the sum, times 4, IS the address)
+//   lane L: low clamp  = lo - (1 + L / 2) cells - (L & 1)  -> words 64 - L .. (distinct per lane; cells of one pattern: pairs of lanes share)
+//           high clamp = hi + 1 + (L / 2) cells + (L & 1)  -> words 66 + bins + L
+// (a + b) << 2 in one instruction: the byte offset of word a + b.  (The compiler distributes the shift over the sum: three.)
+__device__ __forceinline__ uint32_t add_lshl2(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void lds_count(uint32_t lds_byte_address) {               // += 1 on the LDS word at that address
+    __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>(lds_byte_address), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool count_fast_ok(uint32_t lo, uint32_t hi, uint32_t shift) {
+    const unsigned long long margin = (33ull << shift) + 1ull;
+    // float clamps (see the kernel) must be normal numbers, and the high ones at most the infinity pattern; cells of at most 2^18
+    // patterns, because the kernel folds the LDS address of the delta's histogram into `t` as a number of cells
+    return shift <= 18u && (unsigned long long)lo >= margin + 0x00800000ull && (unsigned long long)hi + 1ull + margin <= 0x7f800000ull &&
+           (((unsigned long long)hi + 1ull - lo) & ((1ull << shift) - 1ull)) == 0ull && ((unsigned long long)hi + 1ull - lo) <= (1024ull << shift);
+}
+
+// Three 16-bit deltas (the SDXL x4 job; the second group of a FLUX x8 stripe) fit 5 waves per SIMD.
+// BASE: the inputs are models and a base is subtracted (else they are deltas).
+template <int CAP, bool W32, bool BASE>
 __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_count_kernel(TiesParams p, int d0, int nd) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * TIES_BINS words, then 2 * CAP counters
-    uint32_t *lds_cnt = lds_hist + nd * TIES_BINS;
-    const uint32_t dump = nd * TIES_BINS + 2 * CAP + (threadIdx.x & 63);   // 64 write-only words after the counters
-    for (int i = threadIdx.x; i < nd * TIES_BINS + 2 * CAP; i += MECHA_BLOCK) lds_hist[i] = 0;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * COUNT_STRIDE words
+    for (int i = threadIdx.x; i < nd * COUNT_STRIDE; i += MECHA_BLOCK) lds_hist[i] = 0;
     __syncthreads();
     const long long chunk = (p.total_tiles + gridDim.x - 1) / gridDim.x;
     const long long t0 = (long long)blockIdx.x * chunk;
     const long long t1 = (t0 + chunk < p.total_tiles) ? t0 + chunk : p.total_tiles;
+    const uint32_t lane = threadIdx.x & 63;
     TileCursor cur;
-    uint32_t lo[CAP], width[CAP], shift[CAP], low_mask[CAP];
-    uint32_t below[CAP];                           // per lane: elements with |delta| < lo
-    bool active[CAP];
+    uint32_t lo[CAP], width[CAP], shift[CAP], low_mask[CAP];          // block-uniform
+    uint32_t lob[CAP];                                                 // fast form: lo - 33 cells - (LDS byte address of the delta's words / 8) cells
+    const uint32_t lds_base = (uint32_t)(size_t)(lds_u32 *)lds_hist;   // 16-byte aligned; COUNT_STRIDE is even
+    uint32_t low_clamp[CAP], high_clamp[CAP];                          // fast form: per-lane patterns
+    bool active[CAP], fast[CAP];
 #pragma unroll
-    for (int d = 0; d < CAP; d++) { below[d] = 0; active[d] = false; lo[d] = width[d] = shift[d] = low_mask[d] = 0; }
+    for (int d = 0; d < CAP; d++) { active[d] = fast[d] = false; lo[d] = width[d] = shift[d] = low_mask[d] = lob[d] = low_clamp[d] = high_clamp[d] = 0; }
 
     auto flush = [&](int s) {
+        __syncthreads();
+        const int wave = threadIdx.x >> 6;
+        if (wave < nd) {                                                 // nd <= 4 = waves per block: wave d sums delta d's below words
+            uint32_t *low = lds_hist + wave * COUNT_STRIDE;
+            uint32_t tot = low[lane];
+            low[lane] = 0;
+            if (lane < COUNT_LOW - 64) { tot += low[64 + lane]; low[64 + lane] = 0; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+            if (tot && lane == 0) atomicAdd(&p.counts[(int64_t)s * p.n_deltas + d0 + wave].below, (unsigned long long)tot);
+        }
 #pragma unroll
         for (int d = 0; d < CAP; d++) {
-            if (d < nd && active[d]) {                                   // block-uniform
-                uint32_t tot = below[d];                                 // per lane: sum over the wave
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
-                if (tot && (threadIdx.x & 63) == 0) atomicAdd(&lds_cnt[2 * d], tot);
-            }
-            below[d] = 0;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nd * TIES_BINS; i += MECHA_BLOCK) {
-            const uint32_t c = lds_hist[i];
-            if (c) {
-                const int d = i / TIES_BINS, b = i % TIES_BINS;
-                atomicAdd(p.hist + ((int64_t)s * p.n_deltas + d0 + d) * TIES_BINS + b, c);
-                lds_hist[i] = 0;
-            }
-        }
-        if (threadIdx.x < 2 * nd) {
-            const uint32_t c = lds_cnt[threadIdx.x];
-            if (c) {
-                SelectCounts *sc = p.counts + (int64_t)s * p.n_deltas + d0 + (threadIdx.x >> 1);
-                atomicAdd((threadIdx.x & 1) ? &sc->eq_lo : &sc->below, (unsigned long long)c);
-                lds_cnt[threadIdx.x] = 0;
+            if (d < nd) {
+                // bins past the bracket's last cell hold elements above it (the high clamps' words start there): zeroed, not reported
+                const int limit = fast[d] ? (int)(2u * ((width[d] + 1u) >> shift[d])) : TIES_BINS;
+                uint32_t *w = lds_hist + d * COUNT_STRIDE + COUNT_LOW;
+                for (int b = threadIdx.x; b < TIES_BINS + COUNT_HIGH; b += MECHA_BLOCK) {
+                    const uint32_t c = w[b];
+                    if (c) {
+                        if (b < limit) atomicAdd(p.hist + ((int64_t)s * p.n_deltas + d0 + d) * TIES_BINS + b, c);
+                        w[b] = 0;
+                    }
+                }
             }
         }
         __syncthreads();
     };
 
     // Rolling pipeline over half tiles ("positions": 256 lanes x 8 elements): the loads of position q + 1 are issued BEFORE position q
-    // is consumed, so a wave always has one position's loads in flight while it does another's arithmetic (the VALU time of this
-    // pass is as long as its memory time -- with the arithmetic stubbed out the kernel takes 4.1 ms for the SDXL x4 job, with it
-    // 5.05 -- and issuing a tile's loads only after the previous tile's arithmetic left the two end to end: 5.17 ms).
+    // is consumed, so a wave always has one position's loads in flight while it does another's arithmetic.
     // The load side runs one position ahead with a cursor of its own (`cur`); the compute side follows with the key it is in
     // (`comp_s`) and flushes the block's histograms when that changes.  Two register slots, addressed by compile-time index.
     int valid_u[2], seg_u[2];
@@ -294,7 +328,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_
         if (valid == 0) return;
         const bool vec = p.vec_ok && valid == 8;
         const int64_t e = seg.offset + local;
-        if (p.base != nullptr) rb_u[slot] = load_raw<W32>(vec, p.base, e, valid);
+        if constexpr (BASE) rb_u[slot] = load_raw<W32>(vec, p.base, e, valid);
 #pragma unroll
         for (int d = 0; d < CAP; d++)
             if (d < nd) rv_u[slot][d] = load_raw<W32>(vec, p.in[d0 + d], e, valid);
@@ -312,6 +346,11 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_
                     const SelectState &st = p.state[(int64_t)s_now * p.n_deltas + d0 + d];
                     active[d] = st.mode == MODE_PENDING;
                     lo[d] = st.lo; width[d] = st.hi - st.lo; shift[d] = st.shift; low_mask[d] = (1u << st.shift) - 1u;
+                    fast[d] = count_fast_ok(st.lo, st.hi, st.shift);
+                    lob[d] = st.lo - ((33u + lds_base / 8u + (uint32_t)d * (COUNT_STRIDE / 2)) << st.shift);
+                    const uint32_t odd = st.shift ? (lane & 1u) : 0u;
+                    low_clamp[d] = st.lo - (((lane >> 1) + 1u) << st.shift) - odd;
+                    high_clamp[d] = st.hi + 1u + ((lane >> 1) << st.shift) + odd;
                 }
             }
         }
@@ -321,29 +360,52 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_
         const int valid = valid_u[slot];
         if (!any || valid == 0) return;                                  // every pair of this key was solved by the sample / past the key
         float b[8];
-        if (p.base != nullptr) unpack_raw<W32>(p.in_dt, rb_u[slot], b);
+        if constexpr (BASE) unpack_raw<W32>(p.in_dt, rb_u[slot], b);
         const bool ragged = __ballot(valid < 8) != 0ull;                 // wave-uniform: some lane is at the end of the key
 #pragma unroll
         for (int d = 0; d < CAP; d++) {
             if (d < nd && active[d]) {
                 float v[8];
                 unpack_raw<W32>(p.in_dt, rv_u[slot][d], v);
-                if (p.base != nullptr) {
+                if constexpr (BASE) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];                         // subtract (linear.py:101)
                 }
-                if (ragged) {
+                uint32_t *hist_d = lds_hist + d * COUNT_STRIDE;                              // the compare-and-select form indexes it
+                if (fast[d] && !ragged) {
+                    if constexpr (BASE) {
+                        // |x| and the clamp in one v_med3_f32: patterns of non-negative floats order like the floats, the clamps are
+                        // normal numbers (count_fast_ok), and a delta computed here is never a signalling NaN.  A quiet NaN (from
+                        // non-finite inputs: the key is flagged and dropped) comes out as the low clamp.
+                        const float lc = __uint_as_float(low_clamp[d]), hc = __uint_as_float(high_clamp[d]);
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (j >= valid) v[j] = __uint_as_float(0x7fffffffu);                  // past the key: above every bracket
-                }
+                        for (int j = 0; j < 8; j++) {
+                            const uint32_t t = __float_as_uint(__builtin_amdgcn_fmed3f(__builtin_fabsf(v[j]), lc, hc)) - lob[d];
+                            lds_count(add_lshl2(t >> shift[d], (t + low_mask[d]) >> shift[d]));
+                        }
+                    } else {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t tt = (__float_as_uint(v[j]) & 0x7fffffffu) - lo[d];         // |delta| pattern relative to lo
-                    below[d] += tt >> 31;                                                      // 1 iff |delta| < lo (per lane; summed over the wave at the flush)
-                    // branch-free: values outside the bracket (92% of them) add to a per-lane dump word instead
-                    const uint32_t bin = d * TIES_BINS + bracket_bin(tt, shift[d], low_mask[d]);
-                    atomicAdd(&lds_hist[tt <= width[d] ? bin : dump], 1u);
+                        for (int j = 0; j < 8; j++) {                                           // the same on the integer patterns
+                            const int a = (int)(__float_as_uint(v[j]) & 0x7fffffffu);
+                            const int c = min(max(a, (int)low_clamp[d]), (int)high_clamp[d]);
+                            const uint32_t t = (uint32_t)c - lob[d];
+                            lds_count(add_lshl2(t >> shift[d], (t + low_mask[d]) >> shift[d]));
+                        }
+                    }
+                } else {
+                    if (ragged) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (j >= valid) v[j] = __uint_as_float(0x7fffffffu);                  // past the key: above every bracket
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t tt = (__float_as_uint(v[j]) & 0x7fffffffu) - lo[d];         // |delta| pattern relative to lo
+                        // below the bracket: this lane's counting word; inside: its bin; above: this lane's write-only word
+                        const uint32_t bin = COUNT_LOW + bracket_bin(tt, shift[d], low_mask[d]);
+                        const uint32_t out = (tt >> 31) ? lane : COUNT_LOW + TIES_BINS + lane;
+                        atomicAdd(&hist_d[tt <= width[d] ? bin : out], 1u);
+                    }
                 }
             }
         }
@@ -351,7 +413,6 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_
     const long long q0 = 2 * t0, q1 = 2 * t1;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    // (one slot and no prefetch is 80 VGPRs, 6 waves per SIMD for three deltas: 5.08 ms against 4.95 with this pipeline at 5 waves)
     if (q0 < q1) issue(q0, S0{});
     for (long long q = q0; q < q1; q += 2) {                             // q0 and q1 are even: positions come in pairs
         issue(q + 1, S1{});
@@ -491,6 +552,10 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, 
         st.lo = (st.lo >> st.shift) << st.shift;                          // cells start at lo
         const unsigned long long top = ((((unsigned long long)(st.lo >> st.shift)) + 1024ull) << st.shift) - 1ull;
         if (top < st.hi) st.hi = (uint32_t)top;                           // trims less than one cell off the bracket
+        // the bracket ends with its last cell (hi + 1 - lo a whole number of cells): what the count pass's clamped binning needs
+        // (count_fast_ok); widening by less than a cell costs nothing.  Not past the infinity pattern: such brackets stay ragged.
+        const unsigned long long cell_end = (((unsigned long long)st.hi >> st.shift) << st.shift) + ((1ull << st.shift) - 1ull);
+        if (cell_end <= 0x7f800000ull) st.hi = (uint32_t)cell_end;
     }
     if (threadIdx.x == 0) {
         p.state[sd] = st;
@@ -1794,16 +1859,17 @@ void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
     constexpr int COUNT_GROUP = 4;
     for (int d0 = 0; d0 < p.n_deltas; d0 += COUNT_GROUP) {
         const int nd = (p.n_deltas - d0 < COUNT_GROUP) ? p.n_deltas - d0 : COUNT_GROUP;
-        // LDS: nd histograms, 2 * CAP counters, 64 dump words
-        const int cap = nd <= 2 ? 2 : (nd <= 3 ? 3 : (nd <= 4 ? 4 : 8));
-        const size_t lds = ((size_t)nd * TIES_BINS + 2 * cap + 64) * sizeof(uint32_t);
-        const bool w32 = p.in_dt == MECHA_F32;
-#define MECHA_COUNT_LAUNCH(CAP_, W32_) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd)
+        // LDS: per delta its below words, histogram and write-only words (COUNT_STRIDE)
+        const int cap = nd <= 2 ? 2 : (nd <= 3 ? 3 : 4);
+        const size_t lds = (size_t)nd * COUNT_STRIDE * sizeof(uint32_t);
+        const bool w32 = p.in_dt == MECHA_F32, has_base = p.base != nullptr;
+#define MECHA_COUNT_LAUNCH_B(CAP_, W32_, BASE_) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_, BASE_>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd)
+#define MECHA_COUNT_LAUNCH(CAP_, W32_) do { if (has_base) MECHA_COUNT_LAUNCH_B(CAP_, W32_, true); else MECHA_COUNT_LAUNCH_B(CAP_, W32_, false); } while (0)
         if (cap == 2) { if (w32) MECHA_COUNT_LAUNCH(2, true); else MECHA_COUNT_LAUNCH(2, false); }
         else if (cap == 3) { if (w32) MECHA_COUNT_LAUNCH(3, true); else MECHA_COUNT_LAUNCH(3, false); }
-        else if (cap == 4) { if (w32) MECHA_COUNT_LAUNCH(4, true); else MECHA_COUNT_LAUNCH(4, false); }
-        else { if (w32) MECHA_COUNT_LAUNCH(8, true); else MECHA_COUNT_LAUNCH(8, false); }
+        else { if (w32) MECHA_COUNT_LAUNCH(4, true); else MECHA_COUNT_LAUNCH(4, false); }
 #undef MECHA_COUNT_LAUNCH
+#undef MECHA_COUNT_LAUNCH_B
     }
 }
 
