@@ -262,8 +262,11 @@ __device__ __forceinline__ bool count_fast_ok(uint32_t lo, uint32_t hi, uint32_t
 
 // Three 16-bit deltas (the SDXL x4 job; the second group of a FLUX x8 stripe) fit 5 waves per SIMD.
 // BASE: the inputs are models and a base is subtracted (else they are deltas).
+#ifndef MECHA_COUNT_OCC3
+#define MECHA_COUNT_OCC3 5                   // waves per SIMD of the three-delta 16-bit instantiation (tuning switch)
+#endif
 template <int CAP, bool W32, bool BASE>
-__global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? 5 : 4) void ties_count_kernel(TiesParams p, int d0, int nd) {
+__global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 : 4) void ties_count_kernel(TiesParams p, int d0, int nd) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * COUNT_STRIDE words
     for (int i = threadIdx.x; i < nd * COUNT_STRIDE; i += MECHA_BLOCK) lds_hist[i] = 0;
     __syncthreads();
@@ -1852,7 +1855,10 @@ void launch_hist(const TiesParams &p, unsigned grid, hipStream_t s) {
     }
 }
 
-void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
+#ifndef MECHA_COUNT_BLOCKS_PER_CU
+#define MECHA_COUNT_BLOCKS_PER_CU 0          // 0: as many as the kernel's occupancy (tuning switch)
+#endif
+void launch_count(const TiesParams &p, unsigned looped_grid, hipStream_t s) {
     // 4 histograms per block (33 KiB of LDS, 4 blocks per CU).  7 fit in 64 KiB and read the base once instead of twice for a
     // FLUX x8 job, but at 2 blocks per CU the pass is latency-bound: measured on one FLUX stripe 6.18 ms in one launch of 7
     // against 2 x 2.48 ms in groups of 4 + 3 (groups of 3: 5.56 ms, of 2: 5.77 ms).
@@ -1863,6 +1869,11 @@ void launch_count(const TiesParams &p, unsigned grid, hipStream_t s) {
         const int cap = nd <= 2 ? 2 : (nd <= 3 ? 3 : 4);
         const size_t lds = (size_t)nd * COUNT_STRIDE * sizeof(uint32_t);
         const bool w32 = p.in_dt == MECHA_F32, has_base = p.base != nullptr;
+        // persistent blocks over contiguous tile ranges: exactly as many as are resident at once (5 per CU for three 16-bit deltas,
+        // else 4), so that no second, partly filled round of blocks trails the first
+        const unsigned per_cu = MECHA_COUNT_BLOCKS_PER_CU ? MECHA_COUNT_BLOCKS_PER_CU : ((cap == 3 && !w32) ? (unsigned)MECHA_COUNT_OCC3 : 4u);
+        const unsigned grid = (unsigned)(p.total_tiles < (long long)(256u * per_cu) ? p.total_tiles : 256u * per_cu);
+        (void)looped_grid;
 #define MECHA_COUNT_LAUNCH_B(CAP_, W32_, BASE_) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_, BASE_>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd)
 #define MECHA_COUNT_LAUNCH(CAP_, W32_) do { if (has_base) MECHA_COUNT_LAUNCH_B(CAP_, W32_, true); else MECHA_COUNT_LAUNCH_B(CAP_, W32_, false); } while (0)
         if (cap == 2) { if (w32) MECHA_COUNT_LAUNCH(2, true); else MECHA_COUNT_LAUNCH(2, false); }
