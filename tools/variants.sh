@@ -28,7 +28,7 @@ case "$1" in
     exit $rc ;;
   run)
     cmd=$2; shift 2
-    O=$R/gpurun_out/variants; mkdir -p "$O"
+    O=$R/gpurun_out/variants${VTAG:+_$VTAG}; mkdir -p "$O"
     cp "$R/sd_mecha_amd/libmecha_hip.so" /tmp/libmecha_default.so
     for name in "$@"; do
       cp "$V/lib_$name.so" "$R/sd_mecha_amd/libmecha_hip.so"
@@ -39,7 +39,8 @@ case "$1" in
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 k = d.get("kernels", {})
-print(sys.argv[1], "ms/step", d.get("ms_per_step"), {n: round(v["ms_avg"], 4) for n, v in k.items() if v["ms_avg"] > 0.05})
+avg = {n: (v["ms_avg"] if "ms_avg" in v else v["ms_total"] / max(v["launches"], 1)) for n, v in k.items()}
+print(sys.argv[1], "ms/step", d.get("ms_per_step"), {n: round(a, 4) for n, a in avg.items() if a > 0.05})
 EOF
     done
     cp /tmp/libmecha_default.so "$R/sd_mecha_amd/libmecha_hip.so" ;;
