@@ -60,7 +60,9 @@ struct SelectState {                       // per (key, delta), 64 bytes
 struct SelectCounts { unsigned long long below, eq_lo; };
 struct TiesGlobals { uint32_t n_failed; uint32_t n_pending; unsigned long long n_amb; unsigned long long n_hit; };
 
-struct TileRec { long long elem; int seg; int valid; };     // first element of the tile inside the arena, its key, its element count
+// first element of the tile inside the arena, its key, its element count; the key's offset and size ride along (32 bytes) so that
+// what a flat-grid block needs from the key -- the DARE kernel its mask bit addresses -- is one load away, not two dependent ones
+struct TileRec { long long elem; int seg; int valid; long long seg_offset, seg_numel; };
 
 struct TiesParams {
     const void *base;                      // nullptr: inputs are deltas
@@ -1178,7 +1180,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
     if (p.tile_rec != nullptr) rec = p.tile_rec[t];
     else {
         const long long left = p.seg0.numel - t * TIES_TILE;
-        rec = TileRec{t * TIES_TILE, 0, (int)(left < TIES_TILE ? left : TIES_TILE)};
+        rec = TileRec{t * TIES_TILE, 0, (int)(left < TIES_TILE ? left : TIES_TILE), p.seg0.offset, p.seg0.numel};
     }
     if (rec.valid < TIES_TILE) return;                                                 // ties_merge_kernel's tile
     const int64_t e = rec.elem + (int64_t)u * (MECHA_BLOCK * E) + (int64_t)threadIdx.x * E;
@@ -1203,11 +1205,10 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
     if (!DARE && !key_ok) return;                                                       // ties_merge_kernel's key (same test there)
     uint32_t mbits[N];                                                                  // DARE: this lane's E keep bits per model
     if constexpr (DARE) {
-        const mecha_segment seg = p.tile_rec != nullptr ? p.segs[rec.seg] : p.seg0;
-        const int64_t local = e - seg.offset;
+        const int64_t local = e - rec.seg_offset;
 #pragma unroll
         for (int m = 0; m < N; m++) {
-            const int64_t sbit = (p.mask_stream ? (int64_t)m * seg.numel : (int64_t)m * p.mask_words * 32) + local;
+            const int64_t sbit = (p.mask_stream ? (int64_t)m * rec.seg_numel : (int64_t)m * p.mask_words * 32) + local;
             const uint32_t sh = (uint32_t)(sbit & 31);
             uint32_t w = p.keep_bits[sbit >> 5] >> sh;
             if (sh > 32u - E) w |= p.keep_bits[(sbit >> 5) + 1] << (32u - sh);
@@ -1492,14 +1493,14 @@ __global__ __launch_bounds__(1024) void ties_tile_index_kernel(const mecha_segme
 }
 
 // One record per tile for the flat-grid kernels (one block per segment; a block of the flat merge kernel then needs ONE
-// 16-byte read to know where it is, instead of a binary search over the tile prefix).
+// 32-byte read to know where it is, instead of a binary search over the tile prefix).
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_tile_records_kernel(const mecha_segment *segs, const long long *tile_start, TileRec *rec) {
     const int s = blockIdx.x;
     const mecha_segment seg = segs[s];
     const long long first = tile_start[s], n = tile_start[s + 1] - first;
     for (long long i = threadIdx.x; i < n; i += MECHA_BLOCK) {
         const long long left = seg.numel - i * TIES_TILE;
-        rec[first + i] = TileRec{seg.offset + i * TIES_TILE, s, (int)(left < TIES_TILE ? left : TIES_TILE)};
+        rec[first + i] = TileRec{seg.offset + i * TIES_TILE, s, (int)(left < TIES_TILE ? left : TIES_TILE), seg.offset, seg.numel};
     }
 }
 
