@@ -330,6 +330,54 @@ def test_ties_heavy_ties_and_skewed_keys(amd, oracle, levels):
             assert np.array_equal(host_bits(got), want.view(np.uint32)), (name, k, "output")
 
 
+def test_ties_count_pass_bracket_edges(amd, oracle):
+    """The count pass bins with clamps that need room on both sides of the bracket (ties.hip, "Clamped binning"); brackets at the
+    ends of the pattern range, over many octaves or one pattern wide take its compare-and-select form or the one-pattern cells.
+    Thresholds and outputs stay bit-exact in every case, for fp32 deltas (integer clamps) and for bf16 models minus a base
+    (clamp and |x| in one v_med3_f32), at a ragged key size."""
+    rng = np.random.default_rng(77)
+    n = 600_011                                                       # not a multiple of 8: the key's last position is ragged
+    def mix(*parts):
+        x = np.concatenate([np.asarray(p, dtype=np.float32) for p in parts])
+        x = np.resize(x, n)
+        rng.shuffle(x)
+        return x * rng.choice(np.array([-1.0, 1.0], dtype=np.float32), size=n)
+    cases = {
+        # kth among denormal-range values above a mass of exact zeros: the bracket starts at (or a few patterns above) zero
+        "near_zero": ([mix(np.zeros(n // 2), rng.uniform(1e-42, 3e-39, size=n // 4), rng.normal(0, 0.02, size=n // 4)) for _ in range(3)], (0.35, 0.6)),
+        # kth close to the largest finite patterns: no room for clamp patterns below infinity
+        # (only the first delta holds them: the sum of two would overflow)
+        "near_max": ([mix(rng.uniform(3.0e38, float(np.finfo(np.float32).max), size=n // 3), rng.normal(0, 1.0, size=n - n // 3)),
+                      mix(rng.normal(0, 1.0, size=n))], (0.2, 0.02)),
+        # 60 octaves inside the bracket: cells wider than 2^18 patterns
+        "wide_span": ([mix(np.exp(rng.uniform(np.log(1e-30), np.log(1e30), size=n))) for _ in range(2)], (0.5, 0.2)),
+        # one magnitude only: the bracket is one pattern wide (cells of one pattern)
+        "constant": ([mix(np.full(n, 0.0123)) for _ in range(3)], (0.2, 0.9)),
+        # two neighbouring patterns
+        "two_patterns": ([mix(np.full(n // 2, 0.5), np.full(n - n // 2, np.nextafter(np.float32(0.5), np.float32(1.0)))) for _ in range(2)], (0.5, 0.3)),
+    }
+    for name, (deltas, ks) in cases.items():
+        for k in ks:
+            want, det = oracle.ties_sum(deltas, k=k, details=True)
+            got, thr = amd.ties_sum(*[dev(d, "float32") for d in deltas], k=k, return_thresholds=True)
+            assert np.array_equal(host_bits(thr), det["thresholds"].view(np.uint32)), (name, k, "thresholds")
+            assert np.array_equal(host_bits(got), want.view(np.uint32)), (name, k, "output")
+    # models minus a base in bf16: deltas of a fine-tune (exact zeros, a few coarse levels) and ordinary ones, ragged size
+    base = oracle.from_f32(rng.normal(0, 0.02, size=n).astype(np.float32), "bfloat16")
+    bf = oracle.to_f32(base, "bfloat16")
+    steps = np.array([0.0, 0.0, 0.0, 2.0 ** -12, -(2.0 ** -12), 2.0 ** -11, 2.0 ** -9], dtype=np.float32)
+    models = [oracle.from_f32(bf + steps[rng.integers(0, len(steps), size=n)], "bfloat16") for _ in range(2)]
+    models.append(oracle.from_f32(bf + rng.normal(0, 0.003, size=n).astype(np.float32), "bfloat16"))
+    f32 = [oracle.to_f32(m, "bfloat16") for m in models]
+    for k in (0.2, 0.55, 0.9):
+        ties, det = oracle.ties_sum([oracle.subtract(m, bf) for m in f32], k=k, details=True)
+        want = oracle.from_f32(oracle.add_difference(bf, ties, 1.0), "bfloat16")
+        got, thr = amd.add_difference_ties(dev(base, "bfloat16"), *[dev(m, "bfloat16") for m in models], k=k, alpha=1.0,
+                                           out_dtype=torch.bfloat16, return_thresholds=True)
+        assert np.array_equal(host_bits(thr), det["thresholds"].view(np.uint32)), ("finetune", k, "thresholds")
+        assert np.array_equal(host_bits(got), want), ("finetune", k, "output")
+
+
 @pytest.mark.parametrize("shape", [(5000,), (300, 1280), (64, 32, 3, 3), (7, 1), (1000, 9)])
 def test_ties_sum_extended_model_stock_vs_oracle(amd, oracle, shape):
     """ties_sum_extended with the model-stock factor (ties.py:68-94, :146-159): per-row cosines along the last dimension
