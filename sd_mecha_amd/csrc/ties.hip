@@ -1203,6 +1203,12 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
         }
     }
     if (!DARE && !key_ok) return;                                                       // ties_merge_kernel's key (same test there)
+    // DARE: thresholds may be 0, and zeros (dropped, or genuine +-0) pass `|d| >= 0` but neither vote nor count where a sign is
+    // elected.  The keep test runs against max(thr, smallest denormal): |d| >= 2^-149 is d != 0, and above a positive
+    // threshold nothing changes -- one compare per element instead of two.
+    float thr_k[N];
+#pragma unroll
+    for (int d = 0; d < N; d++) thr_k[d] = DARE ? __builtin_fmaxf(thr[d], __uint_as_float(1u)) : thr[d];
     uint32_t mbits[N];                                                                  // DARE: this lane's E keep bits per model
     if constexpr (DARE) {
         const int64_t local = e - rec.seg_offset;
@@ -1249,11 +1255,11 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                     }
 #pragma unroll
                     for (int j = 0; j < E; j++) {
-                        const float d = v2[j >> 1][j & 1];
-                        bool keep = __builtin_fabsf(d) >= thr[m];                          // filter_top_k (ties.py:128-132)
-                        // DARE: delta * mask (ties.py:33), and thresholds may be 0: zeros (dropped, or genuine +-0) pass the filter but
-                        // neither vote nor count where a sign is elected -- they stay out of `kept`, and -0 never reaches sign_i32
-                        if constexpr (DARE) keep = keep && ((mbits[m] >> j) & 1u) && d != 0.0f;
+                        float d = v2[j >> 1][j & 1];
+                        // DARE: delta * mask (ties.py:33); a dropped delta is +0 and fails the keep test below like any zero (thr_k), so
+                        // zeros stay out of `kept`, and -0 never reaches sign_i32
+                        if constexpr (DARE) d = ((mbits[m] >> j) & 1u) ? d : 0.0f;
+                        const bool keep = __builtin_fabsf(d) >= thr_k[m];                  // filter_top_k (ties.py:128-132)
                         kept[j] += keep ? 1 : 0;
                         f[m][j] = keep ? d : 0.0f;
                         sgn[m][j] = sign_i32(__float_as_int(f[m][j]));
@@ -1295,9 +1301,9 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                     }
 #pragma unroll
                     for (int j = 0; j < E; j++) {
-                        const float d = v2[j >> 1][j & 1];
-                        bool keep = __builtin_fabsf(d) >= thr[m];
-                        if constexpr (DARE) keep = keep && ((mbits[m] >> j) & 1u) && d != 0.0f;
+                        float d = v2[j >> 1][j & 1];
+                        if constexpr (DARE) d = ((mbits[m] >> j) & 1u) ? d : 0.0f;
+                        const bool keep = __builtin_fabsf(d) >= thr_k[m];
                         kept[j] += keep ? 1 : 0;
                         vote[j] += sign_i32(__float_as_int(keep ? d : 0.0f));
                     }
@@ -1320,15 +1326,30 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                         f32x2 g;
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
-                            const float d = v2[q][h];
+                            float d = v2[q][h];
+                            if constexpr (DARE) d = ((mbits[m] >> (2 * q + h)) & 1u) ? d : 0.0f;
                             // kept and of the elected sign (elected 0: only a zero delta could match, and that one is not kept)
-                            bool agree = (__builtin_fabsf(d) >= thr[m]) & (sign_i32(__float_as_int(d)) == fs[2 * q + h]);
-                            if constexpr (DARE) agree = agree && ((mbits[m] >> (2 * q + h)) & 1u) && d != 0.0f;
+                            const bool agree = (__builtin_fabsf(d) >= thr_k[m]) & (sign_i32(__float_as_int(d)) == fs[2 * q + h]);
                             g[h] = agree ? d : 0.0f;
                         }
                         acc[q] = acc[q] + g;
                     }
                 }
+            }
+            // DARE: the three-instruction divisions below (by the count, then by 1 - probability) are exact for sums that are 0 or
+            // lie in [2^-57, 2^59) (the quotient by a count <= 8 then lies in [2^-60, 2^60]); one test of the binary exponents of the
+            // lane's E sums (frexp: 0 for a zero, inf and NaN, which come out as 0 either way) instead of two range tests per
+            // element, and the IEEE divisions behind ONE rarely taken branch.
+            bool slow = false;
+            if constexpr (DARE) {
+                int emin = 0, emax = 0;
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const int ex = __builtin_amdgcn_frexp_expf(acc[j >> 1][j & 1]);
+                    emin = ex < emin ? ex : emin;
+                    emax = ex > emax ? ex : emax;
+                }
+                slow = emin < -56 || emax > 59 || (x.has_rescale && !x.fast_rescale);
             }
             f32x2 r2[P];
 #pragma unroll
@@ -1342,10 +1363,12 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                 if constexpr (DARE) {
                     // with a zero threshold a sum may lie in the denormal range, where the fma form is no longer exact: IEEE division
                     // then; the result is divided by 1 - probability (ties.py:46-50) the same way
+                    if (slow) {
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const uint32_t ab = __float_as_uint(acc[q][h]) & 0x7fffffffu;
-                        if (ab - 1u < 0x12800000u - 1u) qq[h] = acc[q][h] / (float)cnt[2 * q + h];      // 0 < |a| < 2^-90
+                        for (int h = 0; h < 2; h++) {
+                            const uint32_t ab = __float_as_uint(acc[q][h]) & 0x7fffffffu;
+                            if (ab - 1u < 0x12800000u - 1u) qq[h] = acc[q][h] / (float)cnt[2 * q + h];      // 0 < |a| < 2^-90
+                        }
                     }
                 }
                 qq.x = __builtin_amdgcn_class(qq.x, 0x1f8) ? qq.x : 0.0f;              // nan_to_num(nan=0, posinf=0, neginf=0)
@@ -1355,10 +1378,12 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
                         const f32x2 rc = {x.rescale_rcp, x.rescale_rcp}, nd = {-x.rescale_div, -x.rescale_div};
                         const f32x2 s0 = qq * rc;
                         f32x2 sq = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, s0, qq), rc, s0);
+                        if (slow) {
 #pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            const uint32_t ab = __float_as_uint(qq[h]) & 0x7fffffffu;
-                            if (!x.fast_rescale || (ab - 1u < 0x21800000u - 1u) || ab > 0x5d800000u) sq[h] = qq[h] / x.rescale_div;   // outside [2^-60, 2^60]
+                            for (int h = 0; h < 2; h++) {
+                                const uint32_t ab = __float_as_uint(qq[h]) & 0x7fffffffu;
+                                if (!x.fast_rescale || (ab - 1u < 0x21800000u - 1u) || ab > 0x5d800000u) sq[h] = qq[h] / x.rescale_div;   // outside [2^-60, 2^60]
+                            }
                         }
                         qq = sq;
                     }

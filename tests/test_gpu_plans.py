@@ -118,16 +118,27 @@ def test_batched_add_difference_forms_bit_exact(oracle):
                                       0.0, None, _stream()) < 0
 
 
-@pytest.mark.parametrize("n_models,p,k,rescale,vote", [(3, 0.9, 0.2, True, False), (2, 0.4, 0.5, False, False), (7, 0.5, 1.0, True, False),
-                                                        (3, 0.3, 0.35, True, True)])
-def test_batched_dare_vs_oracle(oracle, n_models, p, k, rescale, vote):
+@pytest.mark.parametrize("n_models,p,k,rescale,vote,scale", [(3, 0.9, 0.2, True, False, None), (2, 0.4, 0.5, False, False, None),
+                                                              (7, 0.5, 1.0, True, False, None), (3, 0.3, 0.35, True, True, None),
+                                                              (3, 0.9, 0.2, True, False, 1e-28), (3, 0.5, 0.6, True, False, 2e-37),
+                                                              (2, 0.9, 1.0, True, False, 3e20), (3, 0.7, 0.3, False, False, "mixed")])
+def test_batched_dare_vs_oracle(oracle, n_models, p, k, rescale, vote, scale):
     """Every key's masks are cut from ONE Bernoulli stream (the reference seeds a fresh generator per key, ties.py:29-31):
-    thresholds of the masked deltas bit for bit, outputs bit for bit (vote_sgn: <= 1 ulp, the elected sign of an fp32 sum)."""
+    thresholds of the masked deltas bit for bit, outputs bit for bit (vote_sgn: <= 1 ulp, the elected sign of an fp32 sum).
+    `scale`: deltas far below 2^-57 (down into bf16's denormals), far above 2^59, or all of these beside ordinary ones inside
+    one key -- the sums for which the full-tile kernel leaves its three-instruction divisions for IEEE ones."""
     from sd_mecha_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(23)
     numels = [5, 4096, 1, 70001, 320, 8, 123457, 4097, 640 * 640]
     offs, total, bits, segs, segs_dev = _arena_setup(oracle, rng, numels, n_models + 1)
+    if scale is not None:                                           # base 0: the models ARE the deltas
+        bits[0] = np.zeros_like(bits[0])
+        for i in range(1, n_models + 1):
+            f = oracle.to_f32(bits[i], "bfloat16") * np.float32(50.0)
+            factor = (np.float32(scale) if scale != "mixed"
+                      else rng.choice(np.array([1e-28, 2e-37, 1.0, 3e20], dtype=np.float32), size=f.size))
+            bits[i] = oracle.from_f32((f * factor).astype(np.float32), "bfloat16")
     arenas = [dev(b, "bfloat16") for b in bits]
     n = len(numels)
     seed = 114514
