@@ -332,6 +332,11 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
             in_col[cg][j] = c < key.cols;                                 // cols % 8 == 0: a piece is inside or outside as a whole
             col_at[cg][j] = (int)(in_col[cg][j] ? c : key.cols - 8);
         }
+    // the coalesced side of the 16-bit base / output tiles (see below): row 8 i + crow of a row group, 16-byte piece cpiece of the
+    // wave's 128-byte row
+    const int crow = lane >> 3, cpiece = lane & 7;
+    const bool ccol_ok = bcol0 + wcol + 8 * cpiece < key.cols;
+    const int64_t ccol_at = ccol_ok ? bcol0 + wcol + 8 * cpiece : key.cols - 8;
     if (base == nullptr) {
 #pragma unroll
         for (int rg = 0; rg < 2; rg++)
@@ -353,16 +358,32 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
                         for (int e = 0; e < 4; e++) total[rg][cg][8 * j + 4 * v + e] = w[e];
                     }
     } else {
+        // 16-bit base: a lane's accumulators want 16-byte pieces of 32 different rows, four instructions per 128-byte line.  The
+        // loads are made the other way round -- instruction i of a row group: lane -> (row 8 i + lane / 8, piece lane % 8), whole
+        // lines -- and turned into the accumulator layout through 4 KiB of LDS per wave (the ring stage the prologue leaves free;
+        // pieces XOR-ed by the row so that both sides are conflict-free).  Only this wave touches its 4 KiB: no block barrier.
+        unsigned char *xp = ring + (RING - 1) * STAGE_BYTES + wave * 4096;
 #pragma unroll
-        for (int rg = 0; rg < 2; rg++)
+        for (int rg = 0; rg < 2; rg++) {
+            u32x4 tw[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int64_t row = brow0 + wrow + 32 * rg + 8 * i + crow;
+                tw[i] = *reinterpret_cast<const u32x4 *>(base + (key.offset + (row < last_row ? row : last_row) * key.cols + ccol_at) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(xp + (8 * i + crow) * 128 + ((cpiece ^ crow) << 4)) = tw[i];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int cg = 0; cg < 2; cg++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    const f32x4 w = *reinterpret_cast<const f32x4 *>(base + (row_at[rg] + col_at[cg][j]) * 2);
+                    const u32x4 w = *reinterpret_cast<const u32x4 *>(xp + r * 128 + (((4 * cg + 2 * h + j) ^ (r & 7)) << 4));
 #pragma unroll
-                    for (int e = 0; e < 4; e++) total[rg][cg][4 * j + e] = w[e];
+                    for (int e = 0; e < 4; e++) total[rg][cg][4 * j + e] = __uint_as_float(w[e]);
                 }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     f32x2 poison_in = {0.0f, 0.0f};
     const f32x2 zero2 = {0.0f, 0.0f};
@@ -501,6 +522,39 @@ __device__ __forceinline__ void lora_tile_fast(const LoraParams &p, const mecha_
     char *outp = static_cast<char *>(p.out);
     auto store_out = [&](auto dt_tag) {
         constexpr int ODT = decltype(dt_tag)::value;
+        if constexpr (ODT != MECHA_F32) {
+            // 16-bit output: the tile goes through LDS into whole-line stores (the mirror image of the base loads above).  Any ring
+            // stage but the last one read is free now: every wave left its reads of the round before the last at that round's
+            // barrier, and no DMA is in flight.
+            unsigned char *xp = ring + ((n_chunks + RING - 2) % RING) * STAGE_BYTES + wave * 4096;
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++) {
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) {
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) poison_out = __builtin_elementwise_fma(f32x2{total[rg][cg][i], total[rg][cg][i + 1]}, zero2, poison_out);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        u32x4 w;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float lo = total[rg][cg][8 * j + 2 * e], hi = total[rg][cg][8 * j + 2 * e + 1];
+                            w[e] = ODT == MECHA_BF16 ? (f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16)) : (f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16));
+                        }
+                        *reinterpret_cast<u32x4 *>(xp + r * 128 + (((4 * cg + 2 * h + j) ^ (r & 7)) << 4)) = w;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int64_t row = brow0 + wrow + 32 * rg + 8 * i + crow;
+                    const u32x4 w = *reinterpret_cast<const u32x4 *>(xp + (8 * i + crow) * 128 + ((cpiece ^ crow) << 4));
+                    if (row < key.rows && ccol_ok) *reinterpret_cast<u32x4 *>(outp + (key.offset + row * key.cols + ccol_at) * 2) = w;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
 #pragma unroll
         for (int rg = 0; rg < 2; rg++)
 #pragma unroll
