@@ -46,6 +46,6 @@ for workload, fams in out.items():
         if re.search(r"merge_full_kernel<[5-8],", e["kernel"]):
             e["_note"] = "8-byte-per-lane accesses: outside the guide's calibration, but 2 x FETCH + WRITE equals the algorithmic bytes here too"
         if "lora_kernel" in e["kernel"]:
-            e["_note"] = ("8-byte-per-lane base loads and 16-byte factor loads re-read through L2: outside the guide's calibration; undoubled, FETCH + WRITE = "
+            e["_note"] = ("whole-line base loads and LDS-DMA factor loads re-read through L2: outside the guide's calibration for the doubling; undoubled, FETCH + WRITE = "
                           f"{int((e.get('FETCH_SIZE_KiB', 0.0) + e.get('WRITE_SIZE_KiB', 0.0)) * 1024)} bytes")
 print(json.dumps(out, indent=2))
