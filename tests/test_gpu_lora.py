@@ -42,10 +42,11 @@ def test_lora_golden():
 
 @pytest.mark.parametrize("ldt", ["float16", "bfloat16"])
 def test_lora_many_networks_vs_oracle(oracle, ldt):
-    """16 networks of mixed rank on one key, ragged sizes (not multiples of the 64x64 tile, rank not a multiple of 8)."""
+    """16 networks of mixed rank on one key, ragged sizes (not multiples of the 64x64 tile, rank not a multiple of 8); the last shape
+    takes the fast kernel with partial tiles on both edges (72 rows, 72 columns: one 16-byte piece of a wave's row inside the key)."""
     import sd_mecha_amd as amd
     rng = np.random.default_rng(21)
-    for rows, cols, ranks in [(640, 320 * 9, [32] * 16), (77, 131, [4, 8, 5, 16, 1]), (1280, 1280, [128, 64])]:
+    for rows, cols, ranks in [(640, 320 * 9, [32] * 16), (77, 131, [4, 8, 5, 16, 1]), (1280, 1280, [128, 64]), (200, 1096, [32, 64, 32])]:
         base_b = oracle.from_f32(rng.normal(0, 0.02, size=(rows, cols)).astype(np.float32), "bfloat16")
         acc = oracle.to_f32(base_b, "bfloat16")
         mag = np.abs(acc)
