@@ -78,6 +78,8 @@ def parse_args():
     ap.add_argument("--inputs", default="random", choices=["random", "finetune"],
                     help="random: independent N(0, 0.02^2) checkpoints (SURVEY.md 8d).  finetune: model i = bf16(base + delta_i), delta_i ~ N(0, 0.001^2) "
                          "with 30 / 50 / 70 ... %% of its elements exactly zero: what TIES is run on in practice (few distinct |delta| levels, masses of ties and zeros)")
+    ap.add_argument("--dare-p", type=float, default=0.9, help="sdxl_dare: drop probability (the workload's 0.9 settles every threshold from the masks; "
+                    "below 1 - k = 0.8 the thresholds are positive and the radix-select passes run in full)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time bound of the CPU baseline sample")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end merge() leg (files on tmpfs -> file)")
@@ -96,7 +98,7 @@ def parse_args():
 class Job:
     """One rank's stripe: arenas in HBM + the launch sequence of one step."""
 
-    def __init__(self, workload: str, rank: int, device, inputs: str = "random"):
+    def __init__(self, workload: str, rank: int, device, inputs: str = "random", dare_p: float = 0.9):
         manifest, comps, n_models, recipe, shards = WORKLOADS[workload]
         self.manifest = load_manifest(manifest, comps)
         items = [(k, numel(s)) for k, s, _ in self.manifest]
@@ -135,7 +137,7 @@ class Job:
             self.ws = torch.empty(self.lib.mecha_batched_reduce_workspace_bytes(len(L.keys), L.total_elems), dtype=torch.uint8, device=device)
         if recipe == "dare":
             # the ONE Bernoulli stream every key's masks are cut from (ties.py:29-33), drawn on the host once per job
-            self.dare_p, self.dare_seed = 0.9, 0
+            self.dare_p, self.dare_seed = dare_p, 0
             self.mask_bits = (n_models - 1) * max(L.numels)
             host = torch.empty((self.mask_bits + 31) // 32 + 1, dtype=torch.int32, pin_memory=True)
             t0 = time.perf_counter()
@@ -492,7 +494,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
 
-    job = Job(args.workload, rank, device, args.inputs)
+    job = Job(args.workload, rank, device, args.inputs, args.dare_p)
     for _ in range(args.warmup):
         job.step()
 
