@@ -19,7 +19,9 @@
 //       fixup   : outputs of listed elements that turn out to lie below the final threshold are recomputed
 //     Brackets that miss (kth outside [lo, hi], or an over-full bin: heavy ties) fall back, per (key, delta), to B; the
 //     fallback kernels are always enqueued and exit at once when a device counter says nothing failed (no host sync).
-//  B. radix select (fallback, and the DARE path): hist<1> -> scan<1> -> hist<2> -> scan<2> -> hist<3> -> scan<3>,
+//     DARE (keep masks): pairs whose kth value is one of the dropped zeros are settled from the masks alone (presolve); the others
+//     take this same pipeline on delta * mask -- sample, count, collect and fixup read the keep bits.
+//  B. radix select (fallback; DARE with the model-stock factor): hist<1> -> scan<1> -> hist<2> -> scan<2> -> hist<3> -> scan<3>,
 //     most-significant-digit radix select on the fp32 bit pattern of |delta| (31 value bits split 11 / 11 / 9), LDS
 //     histograms flushed with one global atomic per non-empty bin; three more passes over the inputs.
 //
@@ -209,6 +211,12 @@ __device__ __forceinline__ void apply_keep_bits(const TiesParams &p, int m, int6
     for (int j = 0; j < 8; j++) v[j] = v[j] * (((bits8 >> j) & 1u) ? 1.0f : 0.0f);
 }
 
+// the keep bit of element `local` of delta m of a key of `numel` elements (see apply_keep_bits)
+__device__ __forceinline__ bool keep_bit(const TiesParams &p, int m, int64_t local, int64_t numel) {
+    const int64_t s = (p.mask_stream ? (int64_t)m * numel : (int64_t)m * p.mask_words * 32) + local;
+    return ((p.keep_bits[s >> 5] >> (uint32_t)(s & 31)) & 1u) != 0u;
+}
+
 __device__ __forceinline__ unsigned long long ties_kth(double one_minus_k, int64_t numel) {
     long long kth = (long long)(one_minus_k * (double)numel);       // max(int((1 - k) * numel), 1)  (ties.py:129)
     return (unsigned long long)(kth < 1 ? 1 : kth);
@@ -267,8 +275,10 @@ __device__ __forceinline__ bool count_fast_ok(uint32_t lo, uint32_t hi, uint32_t
 #ifndef MECHA_COUNT_OCC3
 #define MECHA_COUNT_OCC3 5                   // waves per SIMD of the three-delta 16-bit instantiation (tuning switch)
 #endif
-template <int CAP, bool W32, bool BASE>
-__global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 : 4) void ties_count_kernel(TiesParams p, int d0, int nd) {
+// DARE: delta * mask before the binning (ties.py:33): a dropped delta is a zero, below every bracket that has room for the clamps.
+template <int CAP, bool W32, bool BASE, bool DARE = false>
+__global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32 && !DARE) ? MECHA_COUNT_OCC3 : 4) void ties_count_kernel(TiesParams p, int d0, int nd) {
+    if (DARE && p.presolved && p.globals->n_pending == 0) return;           // every pair was settled from its mask
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * COUNT_STRIDE words
     for (int i = threadIdx.x; i < nd * COUNT_STRIDE; i += MECHA_BLOCK) lds_hist[i] = 0;
     __syncthreads();
@@ -319,7 +329,12 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 
     // is consumed, so a wave always has one position's loads in flight while it does another's arithmetic.
     // The load side runs one position ahead with a cursor of its own (`cur`); the compute side follows with the key it is in
     // (`comp_s`) and flushes the block's histograms when that changes.  Two register slots, addressed by compile-time index.
+    int issue_s = -1;                                                    // DARE: the load side's key, and whether any of its pairs is pending
+    bool issue_active = true;
     int valid_u[2], seg_u[2];
+    int64_t local_u[2];                                                  // DARE: the position's first element inside its key (mask bit address)
+    uint32_t mw_u[2][DARE ? CAP : 1][2];                                 // DARE: the mask words of the position, loaded with its data
+    int64_t comp_numel = 0;                                              // DARE: size of the key the compute side is in
     Raw8<W32> rb_u[2], rv_u[2][CAP];
     auto issue = [&](long long q, auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
@@ -328,6 +343,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 
         const mecha_segment seg = cur.seg;
         const int64_t local = (t - cur.first) * TIES_TILE + (int64_t)(q & 1) * (TIES_TILE / 2) + (int64_t)threadIdx.x * 8;
         const int valid = (local >= seg.numel) ? 0 : ((seg.numel - local >= 8) ? 8 : (int)(seg.numel - local));
+        if constexpr (DARE) local_u[slot] = local;
         valid_u[slot] = valid;
         seg_u[slot] = cur.s;
         if (valid == 0) return;
@@ -337,6 +353,16 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 
 #pragma unroll
         for (int d = 0; d < CAP; d++)
             if (d < nd) rv_u[slot][d] = load_raw<W32>(vec, p.in[d0 + d], e, valid);
+        if constexpr (DARE) {
+            // with the data, not when it is consumed: a load issued there would wait behind the next position's (vmcnt is in order)
+#pragma unroll
+            for (int d = 0; d < CAP; d++)
+                if (d < nd) {
+                    const int64_t sb = (p.mask_stream ? (int64_t)(d0 + d) * seg.numel : (int64_t)(d0 + d) * p.mask_words * 32) + local;
+                    mw_u[slot][d][0] = p.keep_bits[sb >> 5];
+                    mw_u[slot][d][1] = ((sb & 31) > 24) ? p.keep_bits[(sb >> 5) + 1] : 0u;       // stream form only (it ends with a pad word)
+                }
+        }
     };
     int comp_s = -1;
     auto consume = [&](auto slot_c) {
@@ -345,6 +371,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 
         if (s_now != comp_s) {
             if (comp_s >= 0) flush(comp_s);
             comp_s = s_now;
+            if constexpr (DARE) comp_numel = get_segment(p, s_now).numel;
 #pragma unroll
             for (int d = 0; d < CAP; d++) {
                 if (d < nd) {
@@ -375,6 +402,14 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 
                 if constexpr (BASE) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];                         // subtract (linear.py:101)
+                }
+                if constexpr (DARE) {                                                       // delta * mask (ties.py:33), see apply_keep_bits
+                    const int64_t sb = (p.mask_stream ? (int64_t)(d0 + d) * comp_numel : (int64_t)(d0 + d) * p.mask_words * 32) + local_u[slot];
+                    const uint32_t sh = (uint32_t)(sb & 31);
+                    uint32_t bits8 = mw_u[slot][d][0] >> sh;
+                    if (sh > 24u) bits8 |= mw_u[slot][d][1] << (32u - sh);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = ((bits8 >> j) & 1u) ? v[j] : 0.0f;
                 }
                 uint32_t *hist_d = lds_hist + d * COUNT_STRIDE;                              // the compare-and-select form indexes it
                 if (fast[d] && !ragged) {
@@ -418,12 +453,45 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32) ? MECHA_COUNT_OCC3 
     const long long q0 = 2 * t0, q1 = 2 * t1;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    if (q0 < q1) issue(q0, S0{});
-    for (long long q = q0; q < q1; q += 2) {                             // q0 and q1 are even: positions come in pairs
-        issue(q + 1, S1{});
-        consume(S0{});
-        if (q + 2 < q1) issue(q + 2, S0{});
-        consume(S1{});
+    if constexpr (DARE) {
+        // most pairs of a DARE job are settled from their masks: the walk jumps over the keys none of whose pairs is pending
+        // (their data is not read, their positions are not visited)
+        long long qi = q0;
+        auto skip = [&]() {
+            while (qi < q1) {
+                cursor_seek(p, qi >> 1, cur);
+                if (cur.s != issue_s) {
+                    issue_s = cur.s;
+                    issue_active = false;
+#pragma unroll
+                    for (int d = 0; d < CAP; d++)
+                        if (d < nd) issue_active |= p.state[(int64_t)cur.s * p.n_deltas + d0 + d].mode == MODE_PENDING;
+                }
+                if (issue_active) break;
+                qi = 2 * cur.end < q1 ? 2 * cur.end : q1;
+            }
+        };
+        skip();
+        bool have0 = qi < q1, have1 = false;
+        if (have0) issue(qi++, S0{});
+        while (have0) {
+            skip();
+            have1 = qi < q1;
+            if (have1) issue(qi++, S1{});
+            consume(S0{});
+            skip();
+            have0 = qi < q1;
+            if (have0) issue(qi++, S0{});
+            if (have1) consume(S1{});
+        }
+    } else {
+        if (q0 < q1) issue(q0, S0{});
+        for (long long q = q0; q < q1; q += 2) {                         // q0 and q1 are even: positions come in pairs
+            issue(q + 1, S1{});
+            consume(S0{});
+            if (q + 2 < q1) issue(q + 2, S0{});
+            consume(S1{});
+        }
     }
     if (comp_s >= 0) flush(comp_s);
 }
@@ -501,6 +569,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, 
     __shared__ uint32_t sel_count;
     const int64_t sd = blockIdx.x;
     const int s = (int)(sd / p.n_deltas), d = (int)(sd % p.n_deltas);
+    if (p.presolved && p.state[sd].mode == MODE_RESOLVED) return;        // DARE: settled from its mask alone (threshold 0)
     const mecha_segment seg = get_segment(p, s);
     const bool whole = seg.numel <= TIES_SAMPLE;
     uint32_t k[16];
@@ -512,6 +581,10 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, 
             if (idx < seg.numel) {
                 float x = load1_rt(p.in_dt, p.in[d], seg.offset + idx);
                 if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, seg.offset + idx);
+                if (p.keep_bits != nullptr) {                             // DARE: delta * mask (ties.py:33)
+                    const int64_t sb = (p.mask_stream ? (int64_t)d * seg.numel : (int64_t)d * p.mask_words * 32) + idx;
+                    if (((p.keep_bits[sb >> 5] >> (sb & 31)) & 1u) == 0u) x = 0.0f;
+                }
                 bits = __float_as_uint(x) & 0x7fffffffu;
             }
             k[i] = bits;
@@ -529,6 +602,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, 
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = v[j] - b[j];
             }
+            if (p.keep_bits != nullptr) apply_keep_bits(p, d, local, seg.numel, v);
 #pragma unroll
             for (int j = 0; j < 8; j++) k[u * 8 + j] = __float_as_uint(v[j]) & 0x7fffffffu;
         }
@@ -569,7 +643,9 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_sample_kernel(TiesParams p, 
     }
 }
 
-__global__ __launch_bounds__(MECHA_BLOCK) void ties_resolve_kernel(TiesParams p, float *thresholds_out, int force_fail) {
+// amb_fails: a pair whose kth value lies in a mixed bin is not listed for the select / fixup kernels but handed to the radix passes
+// like a miss (the DARE form, whose fixup kernels do not exist)
+__global__ __launch_bounds__(MECHA_BLOCK) void ties_resolve_kernel(TiesParams p, float *thresholds_out, int force_fail, int amb_fails = 0) {
     __shared__ unsigned long long wave_tot[MECHA_BLOCK / 64];
     __shared__ int sel;
     __shared__ unsigned long long sel_below;
@@ -598,7 +674,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_resolve_kernel(TiesParams p,
                     st.amb_rank = (uint32_t)(st.kth - sc.below - sc.eq_lo - below);
                     st.amb_count = count;
                     if (st.amb_lo == st.amb_hi) { mode = MODE_RESOLVED; st.threshold_bits = st.amb_lo; }
-                    else if (count <= cap) mode = MODE_AMBIG;
+                    else if (count <= cap && !amb_fails) mode = MODE_AMBIG;
                 }
             }
         }
@@ -881,6 +957,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_collect_kernel(TiesParam
             for (int j = 0; j < valid; j++) {
                 float x = load1_rt(p.in_dt, p.in[m], e + j);
                 if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, e + j);
+                if (p.keep_bits != nullptr && !keep_bit(p, m, e + j - seg.offset, seg.numel)) x = 0.0f;      // DARE: delta * mask
                 const uint32_t bits = __float_as_uint(x) & 0x7fffffffu;
                 if (bits < st.amb_lo || bits > st.amb_hi) continue;
                 const uint32_t slot = atomicAdd(&p.fill[sd], 1u);
@@ -1250,8 +1327,10 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
 #pragma unroll
                     for (int q = 0; q < P; q++) v2[q] = v2[q] - b2[q];                     // subtract (linear.py:101)
                     if (any_amb && amb_hi[m] >= 0.0f) {                                    // wave-uniform and rare
+                        // (DARE: a dropped delta is a zero, never an ambiguous value -- an ambiguous bin starts above its cell's first pattern)
 #pragma unroll
-                        for (int j = 0; j < E; j++) hit |= (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
+                        for (int j = 0; j < E; j++)
+                            hit |= (!DARE || ((mbits[m] >> j) & 1u)) && (__builtin_fabsf(v2[j >> 1][j & 1]) >= thr[m]) && (__builtin_fabsf(v2[j >> 1][j & 1]) <= amb_hi[m]);
                     }
 #pragma unroll
                     for (int j = 0; j < E; j++) {
@@ -1475,9 +1554,11 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_fixup_kernel(TiesParams p, M
         const int64_t e = p.amb_elem[i];
         const SelectState *st = p.state + (int64_t)s * p.n_deltas;
         const float b = (p.base != nullptr) ? load1_rt(p.in_dt, p.base, e) : 0.0f;
+        const mecha_segment seg = get_segment(p, s);
         auto filtered = [&](int m) {
             float f = load1_rt(p.in_dt, p.in[m], e);
             if (p.base != nullptr) f = f - b;
+            if (p.keep_bits != nullptr && !keep_bit(p, m, e - seg.offset, seg.numel)) f = 0.0f;               // DARE: delta * mask (ties.py:33)
             return f * ((__builtin_fabsf(f) >= __uint_as_float(st[m].threshold_bits)) ? 1.0f : 0.0f);
         };
         float vote = 0.0f;
@@ -1491,6 +1572,7 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_fixup_kernel(TiesParams p, M
         }
         float q = acc / cnt;
         if (nonfinite_f32(q)) q = 0.0f;
+        if (x.has_rescale) q = q / x.rescale_div;                            // DARE: / (1 - probability) (ties.py:46-50)
         if (p.base != nullptr) q = __builtin_fmaf(q, x.alpha, b);
         store1_rt(p.out_dt, out, e, q);
         if (nonfinite_f32(q) && flags != nullptr) atomicOr(flags + (p.tile_start == nullptr ? 0 : s), MECHA_FLAG_OUTPUT_NONFINITE);
@@ -1916,10 +1998,14 @@ void launch_count(const TiesParams &p, unsigned looped_grid, hipStream_t s) {
         const bool w32 = p.in_dt == MECHA_F32, has_base = p.base != nullptr;
         // persistent blocks over contiguous tile ranges: exactly as many as are resident at once (5 per CU for three 16-bit deltas,
         // else 4), so that no second, partly filled round of blocks trails the first
-        const unsigned per_cu = MECHA_COUNT_BLOCKS_PER_CU ? MECHA_COUNT_BLOCKS_PER_CU : ((cap == 3 && !w32) ? (unsigned)MECHA_COUNT_OCC3 : 4u);
+        const unsigned per_cu = MECHA_COUNT_BLOCKS_PER_CU ? MECHA_COUNT_BLOCKS_PER_CU : ((cap == 3 && !w32 && p.keep_bits == nullptr) ? (unsigned)MECHA_COUNT_OCC3 : 4u);
         const unsigned grid = (unsigned)(p.total_tiles < (long long)(256u * per_cu) ? p.total_tiles : 256u * per_cu);
         (void)looped_grid;
-#define MECHA_COUNT_LAUNCH_B(CAP_, W32_, BASE_) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_, BASE_>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd)
+#define MECHA_COUNT_LAUNCH_B(CAP_, W32_, BASE_)                                                                                                       \
+    do {                                                                                                                                          \
+        if (p.keep_bits != nullptr) MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_, BASE_, true>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd); \
+        else MECHA_LAUNCH(MK_TIES_COUNT, (ties_count_kernel<CAP_, W32_, BASE_>), dim3(grid), dim3(MECHA_BLOCK), lds, s, p, d0, nd);                 \
+    } while (0)
 #define MECHA_COUNT_LAUNCH(CAP_, W32_) do { if (has_base) MECHA_COUNT_LAUNCH_B(CAP_, W32_, true); else MECHA_COUNT_LAUNCH_B(CAP_, W32_, false); } while (0)
         if (cap == 2) { if (w32) MECHA_COUNT_LAUNCH(2, true); else MECHA_COUNT_LAUNCH(2, false); }
         else if (cap == 3) { if (w32) MECHA_COUNT_LAUNCH(3, true); else MECHA_COUNT_LAUNCH(3, false); }
@@ -2140,6 +2226,26 @@ int run_ties(const TiesCall &c) {
             MECHA_LAUNCH(MK_TIES_MERGE, ties_stock_t_kernel, dim3(tgrid), dim3(MECHA_BLOCK), 0, s, sp, c.n_deltas, (const int64_t *)nullptr);
             MECHA_LAUNCH(MK_TIES_MERGE, (ties_stock_apply_kernel<false>), dim3(sgrid), dim3(MECHA_BLOCK), 0, s, p, sp, x, c.out, c.flags);
         }
+    } else if (dare && !force_radix && max_numel > TIES_SAMPLE) {
+        // DARE: pairs whose kth value is one of the dropped zeros are settled from the masks alone; the others take the bracket select
+        // on the masked deltas (sample + ONE count pass instead of three radix passes), ambiguous values listed and fixed up as in
+        // the TIES form; pairs whose bracket missed take the radix passes (which skip every other key).
+        const int64_t slices = ((max_numel + 31) / 32 + 1 + PRESOLVE_SLICE_WORDS - 1) / PRESOLVE_SLICE_WORDS;
+        MECHA_LAUNCH(MK_TIES_SAMPLE, ties_dare_presolve_kernel, dim3((unsigned)n_sd, (unsigned)slices), dim3(MECHA_BLOCK), 0, s, p);
+        MECHA_LAUNCH(MK_TIES_SAMPLE, ties_dare_presolve_decide_kernel, dim3((unsigned)((n_sd + MECHA_BLOCK - 1) / MECHA_BLOCK)), dim3(MECHA_BLOCK), 0, s, p,
+                     (int64_t)n_sd, one_minus_k, c.thresholds_out);
+        p.presolved = 1;
+        p.bracket = 1;
+        MECHA_LAUNCH(MK_TIES_SAMPLE, ties_sample_kernel, dim3((unsigned)n_sd), dim3(MECHA_BLOCK), 0, s, p, one_minus_k, c.thresholds_out);
+        launch_count(p, grid, s);
+        MECHA_LAUNCH(MK_TIES_RESOLVE, ties_resolve_kernel, dim3((unsigned)n_sd), dim3(MECHA_BLOCK), 0, s, p, c.thresholds_out, force_fail, 0);
+        p.presolved = 0;                                                 // from here on the radix kernels go by MODE_FAILED alone
+        launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s, max_numel);
+        MECHA_LAUNCH(MK_TIES_RESOLVE, ties_amb_offsets_kernel, dim3(1), dim3(1024), 0, s, p, (int64_t)n_sd);
+        launch_merge<true>(p, x, grid, c.out, c.flags, s);
+        MECHA_LAUNCH(MK_TIES_FIXUP, ties_amb_collect_kernel, dim3(64), dim3(MECHA_BLOCK), 0, s, p);
+        MECHA_LAUNCH(MK_TIES_FIXUP, ties_amb_select_kernel, dim3((unsigned)(n_sd < 512 ? n_sd : 512)), dim3(MECHA_BLOCK), 0, s, p, c.thresholds_out, (int64_t)n_sd);
+        MECHA_LAUNCH(MK_TIES_FIXUP, ties_fixup_kernel, dim3(256), dim3(MECHA_BLOCK), 0, s, p, x, c.out, c.flags);
     } else if (!bracket) {
         if (dare) { launch_radix<true>(p, grid, one_minus_k, c.thresholds_out, s, max_numel); launch_merge<true>(p, x, grid, c.out, c.flags, s); }
         else { launch_radix<false>(p, grid, one_minus_k, c.thresholds_out, s); launch_merge<false>(p, x, grid, c.out, c.flags, s); }
