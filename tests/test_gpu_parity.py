@@ -623,6 +623,68 @@ def test_full_config2_job_sampled_keys_vs_oracle(amd, oracle):
         assert np.array_equal(host_bits(job.out[o:o + n]), oracle.from_f32(oracle.add_difference(b32, want, 1.0), "bfloat16")), (L.keys[i], n, "output")
 
 
+@pytest.mark.parametrize("p", [0.9, 0.5])
+def test_full_size_dare_job_thresholds_and_sampled_keys(amd, oracle, p):
+    """The SDXL-shaped DARE job at FULL size (2 529 keys x 3 deltas, every key's masks cut from one Bernoulli stream,
+    ties.py:29-33) in ONE batched launch sequence, as bench.py runs it.  p = 0.9: every kth value is one of the dropped zeros and
+    the thresholds come from the masks' popcounts; p = 0.5: thresholds above zero, bracket select on delta * mask.  Every
+    (key, delta) threshold by its rank property on the masked deltas (ties.py:128-132), counted with torch on the device;
+    thresholds and outputs of a spread of keys bit for bit against the oracle."""
+    import ctypes
+    import pathlib
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    import bench
+    from sd_mecha_amd import _lib
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip("needs 60 GB of free HBM")
+    job = bench.Job("sdxl_dare", 0, torch.device("cuda", 0), dare_p=p)
+    L, lib = job.layout, job.lib
+    n_keys, nd = len(L.keys), job.n_models - 1
+    thr = torch.full((n_keys, nd), -1.0, dtype=torch.float32, device="cuda")
+    job.flags.zero_()
+    st = lib.mecha_batched_add_difference_dare(
+        job.arenas[0].data_ptr(), job.model_ptrs, nd, job.out.data_ptr(), job.segs_dev.data_ptr(), ctypes.addressof(job.segs_host), n_keys,
+        L.total_elems, _lib.BF16, _lib.BF16, 0.2, 1.0, 0, p, 1, job.mask_stream.data_ptr(), job.mask_bits, 0, 0.0, None, None, thr.data_ptr(),
+        job.ws.data_ptr(), job.ws.numel(), job.flags.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(st, "batched dare")
+    torch.cuda.synchronize()
+    assert int(job.flags.abs().sum().item()) == 0
+    # bit s of the stream (word s >> 5, bit s & 31) keeps element s - d * numel of delta d
+    shifts = torch.arange(32, dtype=torch.int32, device="cuda")
+    keep = ((job.mask_stream[:, None] >> shifts) & 1).to(torch.bool).flatten()
+    base = job.arenas[0]
+    bad = []
+    for i, (o, n) in enumerate(zip(L.offsets, L.numels)):
+        kth = max(int((1 - 0.2) * n), 1)
+        b32 = base[o:o + n].float()
+        for d in range(nd):
+            dm = ((job.arenas[1 + d][o:o + n].float() - b32) * keep[d * n:(d + 1) * n]).abs()
+            t = thr[i, d]
+            if not (int((dm < t).sum().item()) < kth <= int((dm <= t).sum().item())):
+                bad.append((L.keys[i], d, float(t)))
+    assert not bad, bad[:5]
+    sizeable = torch.tensor(L.numels, device="cuda") >= 4096        # (a key of a few elements can keep more than its share)
+    if p == 0.9:
+        assert float(thr[sizeable].max()) == 0.0                    # 90 % dropped, kth at 80 %
+    else:
+        assert float(thr[sizeable].min()) > 0.0
+    order = sorted(range(n_keys), key=lambda i: L.numels[i])
+    picks = set(order[:4] + order[len(order) // 2 - 2:len(order) // 2 + 2] + [i for i in order if L.numels[i] <= 4_000_000][-2:]
+                + [i for i in range(n_keys) if L.numels[i] % 4096][:4])
+    for i in sorted(picks):
+        o, n = L.offsets[i], L.numels[i]
+        bits = [host_bits(a[o:o + n]) for a in job.arenas]
+        b32 = oracle.to_f32(bits[0], "bfloat16")
+        deltas = [oracle.subtract(oracle.to_f32(x, "bfloat16"), b32) for x in bits[1:]]
+        masks = oracle.dare_masks(job.dare_seed, p, nd, (n,))
+        _, det = oracle.ties_sum([dl * mk.astype(np.float32) for dl, mk in zip(deltas, masks)], k=0.2, details=True)
+        assert np.array_equal(host_bits(thr[i]), det["thresholds"].view(np.uint32)), (L.keys[i], "thresholds")
+        ties = oracle.ties_sum_with_dropout(deltas, probability=p, rescale=True, k=0.2, apply_stock=True, masks=masks)
+        assert np.array_equal(host_bits(job.out[o:o + n]), oracle.from_f32(oracle.add_difference(b32, ties, 1.0), "bfloat16")), (L.keys[i], n, "output")
+
+
 @pytest.mark.parametrize("workload", ["flux_navg", "flux_ties"])
 def test_full_config3_stripe_vs_oracle(amd, oracle, workload):
     """BASELINE config 3 at one GPU's FULL share -- the keys LPT deals to rank 0 of 8 from the FLUX-dev diffuser (1.49 B
