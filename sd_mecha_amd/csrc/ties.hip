@@ -205,8 +205,10 @@ __device__ __forceinline__ void store_rt(int dt, bool vec, void *ptr, int64_t e,
 __device__ __forceinline__ void apply_keep_bits(const TiesParams &p, int m, int64_t local, int64_t numel, float (&v)[8]) {
     const int64_t s = (p.mask_stream ? (int64_t)m * numel : (int64_t)m * p.mask_words * 32) + local;
     const uint32_t sh = (uint32_t)(s & 31);
-    uint32_t bits8 = p.keep_bits[s >> 5] >> sh;
-    if (sh > 24u) bits8 |= p.keep_bits[(s >> 5) + 1] << (32u - sh);       // stream form only (the stream ends with a pad word)
+    // both words loaded unconditionally (a load under a branch brings its own full wait); the second index only moves where the
+    // 8 bits straddle a word: stream form only, and the stream ends with a pad word
+    const uint32_t w0 = p.keep_bits[s >> 5], w1 = p.keep_bits[(s >> 5) + (sh > 24u ? 1 : 0)];
+    const uint32_t bits8 = __builtin_amdgcn_alignbit(w1, w0, sh);
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = v[j] * (((bits8 >> j) & 1u) ? 1.0f : 0.0f);
 }
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32 && !DARE) ? MECHA_CO
                 if (d < nd) {
                     const int64_t sb = (p.mask_stream ? (int64_t)(d0 + d) * seg.numel : (int64_t)(d0 + d) * p.mask_words * 32) + local;
                     mw_u[slot][d][0] = p.keep_bits[sb >> 5];
-                    mw_u[slot][d][1] = ((sb & 31) > 24) ? p.keep_bits[(sb >> 5) + 1] : 0u;       // stream form only (it ends with a pad word)
+                    mw_u[slot][d][1] = p.keep_bits[(sb >> 5) + (((sb & 31) > 24) ? 1 : 0)];      // unconditional load, see apply_keep_bits
                 }
         }
     };
@@ -406,8 +408,7 @@ __global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32 && !DARE) ? MECHA_CO
                 if constexpr (DARE) {                                                       // delta * mask (ties.py:33), see apply_keep_bits
                     const int64_t sb = (p.mask_stream ? (int64_t)(d0 + d) * comp_numel : (int64_t)(d0 + d) * p.mask_words * 32) + local_u[slot];
                     const uint32_t sh = (uint32_t)(sb & 31);
-                    uint32_t bits8 = mw_u[slot][d][0] >> sh;
-                    if (sh > 24u) bits8 |= mw_u[slot][d][1] << (32u - sh);
+                    const uint32_t bits8 = __builtin_amdgcn_alignbit(mw_u[slot][d][1], mw_u[slot][d][0], sh);
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] = ((bits8 >> j) & 1u) ? v[j] : 0.0f;
                 }
@@ -1254,7 +1255,15 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
     const long long t = (long long)(blockIdx.x / BLOCKS_PER_TILE);
     const int u = (int)(blockIdx.x % BLOCKS_PER_TILE);
     TileRec rec;
-    if (p.tile_rec != nullptr) rec = p.tile_rec[t];
+    // (read through the constant address space: block-uniform, so scalar loads -- the compiler otherwise selects between this
+    //  pointer and the kernel argument's and reads seg_offset with a FLAT vector load, whose wait drains the data loads)
+    if (p.tile_rec != nullptr) {
+        typedef const __attribute__((address_space(4))) long long *const_i64;
+        typedef const __attribute__((address_space(4))) int *const_i32;
+        const TileRec *g = p.tile_rec + t;
+        rec.elem = *(const_i64)&g->elem; rec.seg = *(const_i32)&g->seg; rec.valid = *(const_i32)&g->valid;
+        rec.seg_offset = *(const_i64)&g->seg_offset; rec.seg_numel = *(const_i64)&g->seg_numel;
+    }
     else {
         const long long left = p.seg0.numel - t * TIES_TILE;
         rec = TileRec{t * TIES_TILE, 0, (int)(left < TIES_TILE ? left : TIES_TILE), p.seg0.offset, p.seg0.numel};
@@ -1267,6 +1276,19 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
     const RawWords<E> rb = load_words_nt<E>(base + e);
 #pragma unroll
     for (int m = 0; m < N; m++) rv[m] = load_words_nt<E>(static_cast<const uint16_t *>(p.in[m]) + e);
+    // DARE: this lane's E keep bits per model.  The mask words are loaded here, behind the data and without a branch: loads under
+    // a condition each came with a full wait of their own, three round trips after the data had landed (7.2 ms for the SDXL job)
+    uint32_t mbits[N], mw0[DARE ? N : 1], mw1[DARE ? N : 1], msh[DARE ? N : 1];
+    if constexpr (DARE) {
+        const int64_t local = e - rec.seg_offset;
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int64_t sbit = (p.mask_stream ? (int64_t)m * rec.seg_numel : (int64_t)m * p.mask_words * 32) + local;
+            msh[m] = (uint32_t)(sbit & 31);
+            mw0[m] = p.keep_bits[sbit >> 5];
+            mw1[m] = p.keep_bits[(sbit >> 5) + (msh[m] > 32u - E ? 1 : 0)];             // see apply_keep_bits
+        }
+    }
     float thr[N], amb_hi[N];
     bool key_ok = true, any_amb = false;
     {
@@ -1286,17 +1308,9 @@ __global__ __launch_bounds__(MECHA_BLOCK) void ties_merge_full_kernel(TiesParams
     float thr_k[N];
 #pragma unroll
     for (int d = 0; d < N; d++) thr_k[d] = DARE ? __builtin_fmaxf(thr[d], __uint_as_float(1u)) : thr[d];
-    uint32_t mbits[N];                                                                  // DARE: this lane's E keep bits per model
     if constexpr (DARE) {
-        const int64_t local = e - rec.seg_offset;
 #pragma unroll
-        for (int m = 0; m < N; m++) {
-            const int64_t sbit = (p.mask_stream ? (int64_t)m * rec.seg_numel : (int64_t)m * p.mask_words * 32) + local;
-            const uint32_t sh = (uint32_t)(sbit & 31);
-            uint32_t w = p.keep_bits[sbit >> 5] >> sh;
-            if (sh > 32u - E) w |= p.keep_bits[(sbit >> 5) + 1] << (32u - sh);
-            mbits[m] = w;
-        }
+        for (int m = 0; m < N; m++) mbits[m] = __builtin_amdgcn_alignbit(mw1[m], mw0[m], msh[m]);
     }
     __syncthreads();                                                                    // recip[]
     const f32x2 zero2 = {0.0f, 0.0f};
