@@ -277,9 +277,17 @@ __device__ __forceinline__ bool count_fast_ok(uint32_t lo, uint32_t hi, uint32_t
 #ifndef MECHA_COUNT_OCC3
 #define MECHA_COUNT_OCC3 5                   // waves per SIMD of the three-delta 16-bit instantiation (tuning switch)
 #endif
+// Four fp32 streams (+ base) hold 2 x 5 x 8 registers of raw words in the two slots alone: at 4 waves per SIMD (128 registers) that
+// instantiation spilled 344 of them; it gets 2 waves' worth.
+#ifndef MECHA_COUNT_OCC4_F32
+#define MECHA_COUNT_OCC4_F32 2               // (tuning switch)
+#endif
+constexpr int count_waves_per_simd(int cap, bool w32, bool dare) {
+    return (cap == 3 && !w32 && !dare) ? MECHA_COUNT_OCC3 : ((cap == 4 && w32) ? MECHA_COUNT_OCC4_F32 : 4);
+}
 // DARE: delta * mask before the binning (ties.py:33): a dropped delta is a zero, below every bracket that has room for the clamps.
 template <int CAP, bool W32, bool BASE, bool DARE = false>
-__global__ __launch_bounds__(MECHA_BLOCK, (CAP == 3 && !W32 && !DARE) ? MECHA_COUNT_OCC3 : 4) void ties_count_kernel(TiesParams p, int d0, int nd) {
+__global__ __launch_bounds__(MECHA_BLOCK, count_waves_per_simd(CAP, W32, DARE)) void ties_count_kernel(TiesParams p, int d0, int nd) {
     if (DARE && p.presolved && p.globals->n_pending == 0) return;           // every pair was settled from its mask
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];     // nd * COUNT_STRIDE words
     for (int i = threadIdx.x; i < nd * COUNT_STRIDE; i += MECHA_BLOCK) lds_hist[i] = 0;
@@ -945,27 +953,68 @@ __device__ __forceinline__ float prov_threshold(const SelectState &st) {
 // entries per key).  This kernel re-reads those vectors and appends the ambiguous values to their pairs' lists.
 __global__ __launch_bounds__(MECHA_BLOCK) void ties_amb_collect_kernel(TiesParams p) {
     const unsigned long long n = p.globals->n_hit < p.amb_capacity ? p.globals->n_hit : p.amb_capacity;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * MECHA_BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * MECHA_BLOCK) {
-        const int s = (int)p.hit_seg[i];
-        const int64_t e = p.hit_elem[i];
+    const int lane = threadIdx.x & 63;
+    // every lane of a wave takes the same number of turns (the slots are handed out wave by wave, below)
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * MECHA_BLOCK; i0 < n; i0 += (unsigned long long)gridDim.x * MECHA_BLOCK) {
+        const unsigned long long i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const int s = live ? (int)p.hit_seg[i] : 0;
+        const int64_t e = live ? p.hit_elem[i] : 0;
         const mecha_segment seg = get_segment(p, s);
         const int64_t left = seg.offset + seg.numel - e;
-        const int valid = left >= 8 ? 8 : (int)left;
+        const int valid = !live ? 0 : (left >= 8 ? 8 : (int)left);
         for (int m = 0; m < p.n_deltas; m++) {
             const int64_t sd = (int64_t)s * p.n_deltas + m;
             const SelectState &st = p.state[sd];
-            if (st.mode != MODE_AMBIG) continue;
-            for (int j = 0; j < valid; j++) {
-                float x = load1_rt(p.in_dt, p.in[m], e + j);
-                if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, e + j);
-                if (p.keep_bits != nullptr && !keep_bit(p, m, e + j - seg.offset, seg.numel)) x = 0.0f;      // DARE: delta * mask
-                const uint32_t bits = __float_as_uint(x) & 0x7fffffffu;
-                if (bits < st.amb_lo || bits > st.amb_hi) continue;
-                const uint32_t slot = atomicAdd(&p.fill[sd], 1u);
-                if (slot >= st.amb_count) continue;              // cannot happen: the count pass saw the same elements
-                const unsigned long long at = st.amb_offset + slot;
-                if (at >= p.amb_capacity) continue;
-                p.amb_elem[at] = e + j; p.amb_bits[at] = bits; p.amb_sd[at] = (uint32_t)sd;
+            const bool amb = live && st.mode == MODE_AMBIG;
+            uint32_t vals[8], match = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                vals[j] = 0u;
+                if (amb && j < valid) {
+                    float x = load1_rt(p.in_dt, p.in[m], e + j);
+                    if (p.base != nullptr) x = x - load1_rt(p.in_dt, p.base, e + j);
+                    if (p.keep_bits != nullptr && !keep_bit(p, m, e + j - seg.offset, seg.numel)) x = 0.0f;      // DARE: delta * mask
+                    vals[j] = __float_as_uint(x) & 0x7fffffffu;
+                    if (vals[j] >= st.amb_lo && vals[j] <= st.amb_hi) match |= 1u << j;
+                }
+            }
+            // One atomic per wave and pair, not one per value: continuous-valued fp32 deltas put ~a thousand values into a pair's
+            // list, and a thousand atomics on ONE word took 0.8 ms (a single key of 4 x 134 M fp32 deltas: as long as its merge pass).
+            const int cnt = __builtin_popcount(match);
+            const int sd_key = cnt > 0 ? (int)sd : -1;                   // (pairs < 2^31: the workspace holds a SelectState for each)
+            uint32_t first = 0u;
+            unsigned long long todo = __ballot(cnt > 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int sd_l = __shfl(sd_key, leader, 64);
+                const bool mine = sd_key == sd_l;
+                const int v = mine ? cnt : 0;
+                int incl = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += o;
+                }
+                const int total = __shfl(incl, 63, 64);
+                uint32_t b = 0u;
+                if (lane == leader) b = atomicAdd(&p.fill[sd_l], (uint32_t)total);
+                b = (uint32_t)__shfl((int)b, leader, 64);
+                if (mine) first = b + (uint32_t)(incl - v);
+                todo &= ~__ballot(mine);
+            }
+            if (cnt > 0) {
+                uint32_t slot = first;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if ((match >> j) & 1u) {
+                        const unsigned long long at = st.amb_offset + slot;
+                        if (slot < st.amb_count && at < p.amb_capacity) {    // (slot >= amb_count cannot happen: the count pass saw the same elements)
+                            p.amb_elem[at] = e + j; p.amb_bits[at] = vals[j]; p.amb_sd[at] = (uint32_t)sd;
+                        }
+                        slot++;
+                    }
+                }
             }
         }
     }
@@ -2012,7 +2061,7 @@ void launch_count(const TiesParams &p, unsigned looped_grid, hipStream_t s) {
         const bool w32 = p.in_dt == MECHA_F32, has_base = p.base != nullptr;
         // persistent blocks over contiguous tile ranges: exactly as many as are resident at once (5 per CU for three 16-bit deltas,
         // else 4), so that no second, partly filled round of blocks trails the first
-        const unsigned per_cu = MECHA_COUNT_BLOCKS_PER_CU ? MECHA_COUNT_BLOCKS_PER_CU : ((cap == 3 && !w32 && p.keep_bits == nullptr) ? (unsigned)MECHA_COUNT_OCC3 : 4u);
+        const unsigned per_cu = MECHA_COUNT_BLOCKS_PER_CU ? MECHA_COUNT_BLOCKS_PER_CU : (unsigned)count_waves_per_simd(cap, w32, p.keep_bits != nullptr);
         const unsigned grid = (unsigned)(p.total_tiles < (long long)(256u * per_cu) ? p.total_tiles : 256u * per_cu);
         (void)looped_grid;
 #define MECHA_COUNT_LAUNCH_B(CAP_, W32_, BASE_)                                                                                                       \
